@@ -1,0 +1,132 @@
+/* semseg_hip.h — C ABI of libsemseg_hip.so, the gfx950 (MI355X) kernel library behind the
+ * PSPNet / PSANet train step of hszhao/semseg.
+ *
+ * Conventions (the reference's own native-op convention, lib/psa/src/gpu/operator.h:3-4 and
+ * psamask_cuda.cu:108-128, made explicit): plain device pointers + int sizes, caller allocates every
+ * output, callee launches asynchronously on `stream` and returns 0 (SEMSEG_OK) or a negative code
+ * (-1 invalid argument, -2 launch failure).  No torch types cross this boundary.
+ *
+ * Activations are NHWC fp32 with an explicit channel stride `ld*` (elements per pixel) so channel
+ * slices of concatenated buffers are addressed in place; `M` = N*H*W pixels.  Parameters cross in the
+ * reference's state-dict layouts (conv weight OIHW, BN vectors [C]).
+ */
+#ifndef SEMSEG_HIP_H
+#define SEMSEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- lib/psa native operator (reference: lib/psa/src/gpu/operator.h:3-4; CPU twin
+ * lib/psa/src/cpu/operator.h:3-4; called from lib/psa/functions/psamask.py:18-22,32-35).
+ * NCHW fp32, psa_type 0 = collect, else distribute; destination pre-zeroed by the caller. */
+int semseg_psamask_forward(int psa_type, const float* input, float* output, int num_,
+                           int feature_H_, int feature_W_, int mask_H_, int mask_W_,
+                           int half_mask_H_, int half_mask_W_, hipStream_t stream);
+int semseg_psamask_backward(int psa_type, const float* grad_output, float* grad_input, int num_,
+                            int feature_H_, int feature_W_, int mask_H_, int mask_W_,
+                            int half_mask_H_, int half_mask_W_, hipStream_t stream);
+
+/* ---- nn.Conv2d (reference call sites: model/resnet.py:63-69,108-112,134; model/pspnet.py:15,65,
+ * 69,73,77; dilation surgery model/pspnet.py:49-58; model/psanet.py:25-48).
+ * pack: OIHW -> K-contiguous panels consumed by fwd ([Co_pad][Ci*R*S]) and dgrad
+ * ([Ci_pad][roundup32(Co)*R*S]); either destination may be NULL. */
+int semseg_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_dgrad, int Co, int Ci,
+                             int R, int S, int Co_pad, int Ci_pad, hipStream_t stream);
+/* y[M][Co] = conv(x) (+bias) (+add); stats (optional, [2*Co] fp64, caller-zeroed) receives the
+ * per-channel sum and sum of squares of y for the following BatchNorm.  tile_n in {64,128};
+ * w_fwd must have Co_pad = roundup(Co, tile_n) rows.  Ci % 32 == 0. */
+int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
+                    int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
+                    int dil, const float* bias, const float* add, int ldadd, double* stats,
+                    int tile_n, hipStream_t stream);
+/* dx[N*H*W][Ci] = conv_transpose(dy) (+add).  dy must be readable (zero padded) up to
+ * roundup32(Co) channels; w_dgrad must have roundup(Ci, tile_n) rows. */
+int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
+                      int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                      int pad, int dil, const float* add, int ldadd, int tile_n,
+                      hipStream_t stream);
+/* dw_oihw[Co][Ci][R][S] (=|+=) sum over pixels; scratch holds the split-K partial slabs
+ * (>= semseg_conv_wgrad_scratch_floats(...) floats; more slabs => more K parallelism).
+ * dy must be readable (zero padded) up to roundup(Co, 64 or 128) channels.  Ci % 64 == 0. */
+int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
+                      float* scratch, size_t scratch_floats, int N, int H, int W, int Ci, int Ho,
+                      int Wo, int Co, int R, int S, int stride, int pad, int dil, int accumulate,
+                      hipStream_t stream);
+size_t semseg_conv_wgrad_scratch_floats(int Ci, int Co, int R, int S);
+
+/* Stem conv 3->64, 3x3 stride 2 pad 1, reading the caller's NCHW input (model/resnet.py:108). */
+int semseg_stem_conv_fwd(const float* x_nchw, const float* w_oihw, float* y_nhwc, int N, int H,
+                         int W, int Co, hipStream_t stream);
+int semseg_stem_conv_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, int N, int H,
+                           int W, int Co, int accumulate, hipStream_t stream);
+
+/* ---- nn.BatchNorm2d / nn.SyncBatchNorm (+ReLU, +residual, +Dropout2d) — model/resnet.py:64-69,
+ * 88-92,109-113,136; model/pspnet.py:16-17,66-68,74-76; tool/train.py:142.
+ * stats / sums are [2*C] fp64 vectors (caller-zeroed): exactly what SyncBN all-reduces. */
+int semseg_channel_stats(const float* x, int ldx, double* stats, int M, int C, hipStream_t stream);
+int semseg_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, long long* num_batches_tracked,
+                       float momentum, float eps, float* mean, float* invstd, float* scale,
+                       float* shift, int C, hipStream_t stream);
+int semseg_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, float* scale, float* shift, int C,
+                          hipStream_t stream);
+/* out = [relu]( y*scale+shift (+ y2*scale2+shift2) (+ res) ) (* dropmask[n][c]) */
+int semseg_bn_apply(const float* y, int ldy, const float* scale, const float* shift,
+                    const float* y2, int ldy2, const float* scale2, const float* shift2,
+                    const float* res, int ldres, const float* dropmask, float* out, int ldout,
+                    int M, int C, int HW, int relu, hipStream_t stream);
+/* g = dout (*dropmask) (*[out>0]); sums += {sum g, sum g*xhat}; g optionally written. */
+int semseg_bn_bwd_reduce(const float* dout, int lddout, const float* out, int ldout,
+                         const float* dropmask, int HW, const float* y, int ldy, const float* mean,
+                         const float* invstd, float* g, int ldg, double* sums, int M, int C,
+                         hipStream_t stream);
+/* dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count) */
+int semseg_bn_bwd_apply(const float* g, int ldg, const float* y, int ldy, const float* mean,
+                        const float* invstd, const float* gamma, const double* sums, double count,
+                        float* dy, int lddy, int M, int C, hipStream_t stream);
+int semseg_bn_param_grads(const double* sums, float* dgamma, float* dbeta, int C, int accumulate,
+                          hipStream_t stream);
+
+/* ---- spatial ops: MaxPool2d(3,2,1) model/resnet.py:115; AdaptiveAvgPool2d model/pspnet.py:14;
+ * F.interpolate(bilinear, align_corners=True) model/pspnet.py:25,95,100; model/psanet.py:61,78,97. */
+int semseg_maxpool3x3s2_fwd(const float* x, float* y, uint32_t* idx, int N, int H, int W, int C,
+                            hipStream_t stream);
+int semseg_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx, float* dx, int N, int H, int W,
+                            int C, hipStream_t stream);
+int semseg_adaptive_avgpool_fwd(const float* x, int ldx, float* y, const int* bins, int nbins,
+                                int N, int H, int W, int C, hipStream_t stream);
+int semseg_adaptive_avgpool_bwd(const float* base, int ldbase, const float* dpool, float* dx,
+                                int lddx, const int* bins, int nbins, int N, int H, int W, int C,
+                                hipStream_t stream);
+int semseg_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi, int Ho,
+                        int Wo, int C, hipStream_t stream);
+int semseg_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hi, int Wi,
+                        int Ho, int Wo, int C, hipStream_t stream);
+int semseg_bilinear_nhwc_to_nchw(const float* x, int ldx, float* y, int N, int Hi, int Wi, int Ho,
+                                 int Wo, int C, hipStream_t stream);
+
+/* ---- fused head: upsample + CrossEntropyLoss(ignore_index) + argmax — model/pspnet.py:95,100-103,
+ * tool/train.py:121.  acc2 = {sum of losses, valid-pixel count} (fp64), loss = acc2[0]/acc2[1]. */
+int semseg_ce_head_fwd(const float* scores, int ld, const long long* label, float* lse,
+                       long long* pred, double* acc2, float* loss, int N, int h, int w, int H, int W,
+                       int C, int ignore_index, hipStream_t stream);
+int semseg_ce_head_bwd(const float* scores, int ld, const long long* label, const float* lse,
+                       const double* acc2, const float* grad_loss, float grad_mul, float* dscores,
+                       int lddz, int accumulate, int N, int h, int w, int H, int W, int C,
+                       int ignore_index, hipStream_t stream);
+
+/* ---- torch.optim.SGD step (tool/train.py:140,276) over a flat range. */
+int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, float lr, const float* lr_dev,
+                    float momentum, float weight_decay, float grad_scale, int first_step,
+                    hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMSEG_HIP_H */

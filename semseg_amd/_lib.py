@@ -1,0 +1,70 @@
+"""ctypes binding of libsemseg_hip.so.  Prototypes are parsed from include/semseg_hip.h so the header
+is the single source of truth for the C ABI.  There is NO fallback: if the library is missing or a
+symbol is absent, importing/using the ops raises."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(HERE, "..", "include", "semseg_hip.h")
+LIB_PATH = os.path.join(HERE, "csrc", "libsemseg_hip.so")
+
+_CT = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
+    "size_t": ctypes.c_size_t, "hipStream_t": ctypes.c_void_p,
+}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(ctype, argname), ...])}"""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t)\s+(semseg_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        alist = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            if not a:
+                continue
+            if "*" in a:
+                ct = ctypes.c_void_p
+                an = a.split("*")[-1].strip()
+            else:
+                parts = a.split()
+                an = parts[-1]
+                ty = " ".join(p for p in parts[:-1] if p != "const")
+                ct = _CT[ty]
+            alist.append((ct, an))
+        protos[name] = (_CT[ret], alist)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+        self._fn = {}
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    "libsemseg_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; "
+                    "g.build()'` or `python -m semseg_amd.build`. There is no CPU fallback." % LIB_PATH)
+            self._dll = ctypes.CDLL(LIB_PATH)
+            for name, (ret, args) in parse_header().items():
+                f = getattr(self._dll, name)  # AttributeError if the symbol is missing
+                f.restype = ret
+                f.argtypes = [a[0] for a in args]
+                self._fn[name] = f
+        return self
+
+    def __getattr__(self, name):
+        self.load()
+        try:
+            return self._fn[name]
+        except KeyError:
+            raise AttributeError(name)
+
+
+lib = _Lib()

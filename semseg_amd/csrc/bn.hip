@@ -1,0 +1,343 @@
+// BatchNorm2d / SyncBatchNorm (train + eval), fused with ReLU, residual add, the downsample branch
+// and Dropout2d, over NHWC fp32 activations.  Reference semantics: torch nn.BatchNorm2d as built at
+// model/resnet.py:64,67,69,109-113,136 and model/pspnet.py:16,66,74 (eps 1e-5, momentum 0.1, biased
+// variance for normalisation, unbiased into running_var), Bottleneck tail model/resnet.py:88-92,
+// Dropout2d model/pspnet.py:68,76.
+//
+// All per-channel statistics are accumulated in fp64 (per-thread fp64 partials, fp64 hardware
+// atomics) so E[x^2]-E[x]^2 has no cancellation problem; the [2C] fp64 sum vectors are also exactly
+// what SyncBN all-reduces over RCCL (tool/train.py:142 behaviour).  These kernels are HBM-bound:
+// every access is a 16-byte lane access, consecutive lanes on consecutive channels.
+#include "common.h"
+#include "../../include/semseg_hip.h"
+
+namespace {
+
+struct Tiling {
+  int tpr;    // threads along channels (power of two <= 256)
+  int rpb;    // rows per block pass
+  int gx;     // column groups
+};
+
+inline Tiling make_tiling(int CV) {
+  Tiling t;
+  int tpr = 1;
+  while (tpr * 2 <= CV && tpr * 2 <= 256) tpr *= 2;
+  t.tpr = tpr;
+  t.rpb = 256 / tpr;
+  t.gx = (CV + tpr - 1) / tpr;
+  return t;
+}
+
+inline int rows_grid(int M, int rpb, int gx) {
+  int gy = (M + rpb - 1) / rpb;
+  int cap = 2048 / gx;
+  if (cap < 1) cap = 1;
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  return gy;
+}
+
+// block-level reduce of NV doubles per thread across the rpb row-lanes, then fp64 atomics
+template <int NV>
+__device__ __forceinline__ void block_reduce_atomic(double (&v)[NV], int tpr, int rpb, int tr,
+                                                    int tc, double* smem,
+                                                    double* const (&dst)[NV], bool active) {
+  // smem: [rpb][tpr][NV]
+  if (rpb > 1) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) smem[(tr * tpr + tc) * NV + k] = v[k];
+    __syncthreads();
+    if (tr == 0) {
+      for (int r = 1; r < rpb; ++r)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] += smem[(r * tpr + tc) * NV + k];
+    }
+  }
+  if (tr == 0 && active) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) atomic_add_f64(dst[k], v[k]);
+  }
+}
+
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int ldx,
+                                                            double* __restrict__ stats, int M,
+                                                            int C, int tpr, int rpb) {
+  extern __shared__ double sred[];
+  const int CV = C >> 2;
+  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+  const int c4 = blockIdx.x * tpr + tc;
+  const bool active = c4 < CV;
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (active) {
+    for (int m = blockIdx.y * rpb + tr; m < M; m += gridDim.y * rpb) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + c4 * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double d = (double)a[k];
+        v[k] += d;
+        v[4 + k] += d * d;
+      }
+    }
+  }
+  double* dst[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    dst[k] = stats + c4 * 4 + k;
+    dst[4 + k] = stats + C + c4 * 4 + k;
+  }
+  block_reduce_atomic<8>(v, tpr, rpb, tr, tc, sred, dst, active);
+}
+
+// sums -> mean / invstd / scale / shift; running-stat update (train)
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, long long* nbt,
+                                   float momentum, float eps, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  const double mu = stats[c] / count;
+  double var = stats[C + c] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float m = (float)mu;
+  mean[c] = m;
+  invstd[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - m * sc;
+  if (running_mean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_params_kernel(const float* __restrict__ gamma,
+                                      const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv,
+                                      float eps, float* __restrict__ scale,
+                                      float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+struct ApplyArgs {
+  const float* y; const float* scale; const float* shift;
+  const float* y2; const float* scale2; const float* shift2;
+  const float* res; const float* dropmask;
+  float* out;
+  int ldy, ldy2, ldres, ldout;
+  int M, C, HW, relu;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
+  const int CV = p.C >> 2;
+  const size_t total = (size_t)p.M * CV;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * 256) {
+    const int m = (int)(idx / CV);
+    const int c = (int)(idx - (size_t)m * CV) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.y + (size_t)m * p.ldy + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c);
+    v = v * sc + sh;
+    if (p.y2) {
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p.y2 + (size_t)m * p.ldy2 + c);
+      const f32x4 sc2 = *reinterpret_cast<const f32x4*>(p.scale2 + c);
+      const f32x4 sh2 = *reinterpret_cast<const f32x4*>(p.shift2 + c);
+      v += v2 * sc2 + sh2;
+    }
+    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + c);
+    if (p.relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+    }
+    if (p.dropmask) {
+      const int n = m / p.HW;
+      v *= *reinterpret_cast<const f32x4*>(p.dropmask + (size_t)n * p.C + c);
+    }
+    *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.ldout + c) = v;
+  }
+}
+
+struct BwdReduceArgs {
+  const float* dout; const float* out; const float* dropmask;
+  const float* y; const float* mean; const float* invstd;
+  float* g; double* sums;
+  int lddout, ldout, ldy, ldg;
+  int M, C, HW, tpr, rpb;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdReduceArgs p) {
+  extern __shared__ double sred[];
+  const int CV = p.C >> 2;
+  const int tc = threadIdx.x % p.tpr, tr = threadIdx.x / p.tpr;
+  const int c4 = blockIdx.x * p.tpr + tc;
+  const bool active = c4 < CV;
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (active) {
+    const int c = c4 * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(p.invstd + c);
+    for (int m = blockIdx.y * p.rpb + tr; m < p.M; m += gridDim.y * p.rpb) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(p.dout + (size_t)m * p.lddout + c);
+      if (p.dropmask) {
+        const int n = m / p.HW;
+        g *= *reinterpret_cast<const f32x4*>(p.dropmask + (size_t)n * p.C + c);
+      }
+      if (p.out) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(p.out + (size_t)m * p.ldout + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+      }
+      if (p.g) *reinterpret_cast<f32x4*>(p.g + (size_t)m * p.ldg + c) = g;
+      const f32x4 yy = *reinterpret_cast<const f32x4*>(p.y + (size_t)m * p.ldy + c);
+      const f32x4 xh = (yy - mu) * is;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] += (double)g[k];
+        v[4 + k] += (double)g[k] * (double)xh[k];
+      }
+    }
+  }
+  double* dst[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    dst[k] = p.sums + c4 * 4 + k;
+    dst[4 + k] = p.sums + p.C + c4 * 4 + k;
+  }
+  block_reduce_atomic<8>(v, p.tpr, p.rpb, tr, tc, sred, dst, active);
+}
+
+struct BwdApplyArgs {
+  const float* g; const float* y; const float* mean; const float* invstd; const float* gamma;
+  const double* sums;
+  float* dy;
+  double inv_count;
+  int ldg, ldy, lddy;
+  int M, C;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p) {
+  const int CV = p.C >> 2;
+  const size_t total = (size_t)p.M * CV;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * 256) {
+    const int m = (int)(idx / CV);
+    const int c = (int)(idx - (size_t)m * CV) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.g + (size_t)m * p.ldg + c);
+    const f32x4 yy = *reinterpret_cast<const f32x4*>(p.y + (size_t)m * p.ldy + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(p.invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float mg = (float)(p.sums[c + k] * p.inv_count);
+      const float mgx = (float)(p.sums[p.C + c + k] * p.inv_count);
+      const float xh = (yy[k] - mu[k]) * is[k];
+      r[k] = ga[k] * is[k] * (g[k] - mg - xh * mgx);
+    }
+    *reinterpret_cast<f32x4*>(p.dy + (size_t)m * p.lddy + c) = r;
+  }
+}
+
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* dgamma, float* dbeta,
+                                      int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float dg = (float)sums[C + c], db = (float)sums[c];
+  dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+  dbeta[c] = accumulate ? dbeta[c] + db : db;
+}
+
+inline int flat_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int semseg_channel_stats(const float* x, int ldx, double* stats, int M, int C, hipStream_t stream) {
+  if (!x || !stats || (C & 3) || (ldx & 3) || M <= 0) return SEMSEG_EINVAL;
+  const Tiling t = make_tiling(C >> 2);
+  dim3 grid(t.gx, rows_grid(M, t.rpb, t.gx));
+  channel_stats_kernel<<<grid, 256, 256 * 8 * sizeof(double), stream>>>(x, ldx, stats, M, C, t.tpr, t.rpb);
+  return semseg_launch_status();
+}
+
+int semseg_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, long long* num_batches_tracked,
+                       float momentum, float eps, float* mean, float* invstd, float* scale,
+                       float* shift, int C, hipStream_t stream) {
+  if (!stats || !gamma || !beta || !mean || !invstd || !scale || !shift || count <= 0) return SEMSEG_EINVAL;
+  bn_finalize_kernel<<<(C + 255) / 256, 256, 0, stream>>>(stats, count, gamma, beta, running_mean,
+                                                        running_var, num_batches_tracked, momentum,
+                                                        eps, mean, invstd, scale, shift, C);
+  return semseg_launch_status();
+}
+
+int semseg_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, float* scale, float* shift, int C,
+                          hipStream_t stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return SEMSEG_EINVAL;
+  bn_eval_params_kernel<<<(C + 255) / 256, 256, 0, stream>>>(gamma, beta, running_mean, running_var,
+                                                           eps, scale, shift, C);
+  return semseg_launch_status();
+}
+
+int semseg_bn_apply(const float* y, int ldy, const float* scale, const float* shift,
+                    const float* y2, int ldy2, const float* scale2, const float* shift2,
+                    const float* res, int ldres, const float* dropmask, float* out, int ldout,
+                    int M, int C, int HW, int relu, hipStream_t stream) {
+  if (!y || !scale || !shift || !out || (C & 3) || (ldy & 3) || (ldout & 3)) return SEMSEG_EINVAL;
+  if (y2 && (!scale2 || !shift2 || (ldy2 & 3))) return SEMSEG_EINVAL;
+  if (res && (ldres & 3)) return SEMSEG_EINVAL;
+  ApplyArgs a{y, scale, shift, y2, scale2, shift2, res, dropmask, out,
+              ldy, ldy2, ldres, ldout, M, C, HW, relu};
+  bn_apply_kernel<<<flat_grid((size_t)M * (C >> 2)), 256, 0, stream>>>(a);
+  return semseg_launch_status();
+}
+
+int semseg_bn_bwd_reduce(const float* dout, int lddout, const float* out, int ldout,
+                         const float* dropmask, int HW, const float* y, int ldy, const float* mean,
+                         const float* invstd, float* g, int ldg, double* sums, int M, int C,
+                         hipStream_t stream) {
+  if (!dout || !y || !mean || !invstd || !sums || (C & 3) || (lddout & 3) || (ldy & 3)) return SEMSEG_EINVAL;
+  const Tiling t = make_tiling(C >> 2);
+  BwdReduceArgs a{dout, out, dropmask, y, mean, invstd, g, sums,
+                  lddout, ldout, ldy, ldg, M, C, HW, t.tpr, t.rpb};
+  dim3 grid(t.gx, rows_grid(M, t.rpb, t.gx));
+  bn_bwd_reduce_kernel<<<grid, 256, 256 * 8 * sizeof(double), stream>>>(a);
+  return semseg_launch_status();
+}
+
+int semseg_bn_bwd_apply(const float* g, int ldg, const float* y, int ldy, const float* mean,
+                        const float* invstd, const float* gamma, const double* sums, double count,
+                        float* dy, int lddy, int M, int C, hipStream_t stream) {
+  if (!g || !y || !mean || !invstd || !gamma || !sums || !dy || (C & 3) || count <= 0) return SEMSEG_EINVAL;
+  BwdApplyArgs a{g, y, mean, invstd, gamma, sums, dy, 1.0 / count, ldg, ldy, lddy, M, C};
+  bn_bwd_apply_kernel<<<flat_grid((size_t)M * (C >> 2)), 256, 0, stream>>>(a);
+  return semseg_launch_status();
+}
+
+int semseg_bn_param_grads(const double* sums, float* dgamma, float* dbeta, int C, int accumulate,
+                          hipStream_t stream) {
+  if (!sums || !dgamma || !dbeta) return SEMSEG_EINVAL;
+  bn_param_grads_kernel<<<(C + 255) / 256, 256, 0, stream>>>(sums, dgamma, dbeta, C, accumulate);
+  return semseg_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+// Implicit-GEMM convolution for gfx950: forward, data-gradient and weight-gradient of the
+// PSPNet/PSANet convolutions (reference: model/resnet.py:63-69,108-112,134; model/pspnet.py:15,
+// 49-58,65,69,73,77; model/psanet.py:25-48 — all nn.Conv2d, fp32).
+//
+// Layout: activations NHWC fp32 with an explicit channel stride (ld) so channel-concatenated
+// buffers (PPM/PSA concat) are addressed in place.  Weights are re-packed once per optimizer step
+// (pack_weights below) into a K-contiguous "B^T" panel whose K order is
+//   k = ((c / 32) * R*S + tap) * 32 + (c % 32)
+// i.e. all taps of one 32-channel chunk are adjacent, so the 9 shifted re-reads of a 3x3 tap loop
+// stay L1/L2-resident.  Arithmetic is exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Tile: 256 threads = 4 waves (2x2), block tile BM x BN x 32, each wave (BM/2)x(BN/2) as
+// 32x32 MFMA blocks; global->register prefetch of K-step t+1 overlaps the MFMAs of step t.
+#include "common.h"
+#include "../../include/semseg_hip.h"
+
+namespace {
+
+constexpr int BK = 32;   // K-step (floats)
+constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 conflict-free
+
+struct ConvArgs {
+  const float* x;   // A source: activations (fwd) or output-gradient (dgrad), NHWC
+  const float* w;   // packed B^T panel [Nout_pad][KT*32]
+  float* y;         // output [M][ldy]
+  const float* bias;  // optional [Nout]
+  const float* add;   // optional [M][ldadd] added in the epilogue
+  double* stats;      // optional [2*Nout]: per-channel sum, sum of squares (fp64 atomics)
+  int ldx, ldy, ldadd;
+  int N, Hin, Win;    // spatial dims of the A source
+  int Hout, Wout;     // spatial dims of the output
+  int Kc;             // channels of the A source per tap (multiple of 32)
+  int Nout;           // valid output channels
+  int R, S, stride, pad, dil;
+  int M;              // N*Hout*Wout
+  int tiles_n;
+};
+
+template <int BM, int BN, bool TR>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int MREP = BM / 64, NREP = BN / 64;
+  constexpr int A_PER = BM / 32, B_PER = BN / 32;
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = logical % p.tiles_n;
+  const int tile_m = logical / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int RS = p.R * p.S;
+  const int nchunk = p.Kc / BK;
+  const int KT = RS * nchunk;
+  const size_t wK = (size_t)KT * BK;  // packed panel row length
+
+  // ---- per-thread staging assignment ----
+  const int kq = tid & 7;     // which float4 of the 32-float K-step
+  const int lrow = tid >> 3;  // 0..31
+  int a_n[A_PER], a_oh[A_PER], a_ow[A_PER];
+  bool a_ok[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int hw = p.Hout * p.Wout;
+    a_n[i] = mm / hw;
+    const int rem = mm - a_n[i] * hw;
+    a_oh[i] = rem / p.Wout;
+    a_ow[i] = rem - a_oh[i] * p.Wout;
+  }
+  const float* bptr[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) bptr[i] = p.w + (size_t)(n0 + lrow + 32 * i) * wK + kq * 4;
+
+  f32x4 ra[A_PER], rb[B_PER];
+
+  auto prefetch = [&](int kt) {
+    const int chunk = kt / RS;
+    const int tap = kt - chunk * RS;
+    const int r = tap / p.S;
+    const int s = tap - r * p.S;
+    const int coff = chunk * BK + kq * 4;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      int ih, iw;
+      bool ok = a_ok[i];
+      if (!TR) {
+        ih = a_oh[i] * p.stride + r * p.dil - p.pad;
+        iw = a_ow[i] * p.stride + s * p.dil - p.pad;
+        ok = ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
+      } else {
+        const int th = a_oh[i] + p.pad - r * p.dil;
+        const int tw = a_ow[i] + p.pad - s * p.dil;
+        ok = ok && th >= 0 && tw >= 0;
+        if (p.stride == 1) {
+          ih = th;
+          iw = tw;
+        } else {
+          ih = th / p.stride;
+          iw = tw / p.stride;
+          ok = ok && (ih * p.stride == th) && (iw * p.stride == tw);
+        }
+        ok = ok && ih < p.Hin && iw < p.Win;
+      }
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const size_t off = ((size_t)(a_n[i] * p.Hin + ih) * p.Win + iw) * p.ldx + coff;
+        v = *reinterpret_cast<const f32x4*>(p.x + off);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + (size_t)kt * BK);
+  };
+
+  f32x16 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  prefetch(0);
+  for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+      *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * LDK + kq * 4]) = rb[i];
+    __syncthreads();
+    if (kt + 1 < KT) prefetch(kt + 1);
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8) {
+      f32x4 a[MREP], b[NREP];
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+        a[i] = *reinterpret_cast<const f32x4*>(
+            &As[(wm * (BM / 2) + i * 32 + l31) * LDK + k8 * 8 + lhi * 4]);
+#pragma unroll
+      for (int j = 0; j < NREP; ++j)
+        b[j] = *reinterpret_cast<const f32x4*>(
+            &Bs[(wn * (BN / 2) + j * 32 + l31) * LDK + k8 * 8 + lhi * 4]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: store, optional bias / residual add, optional fp64 channel statistics ----
+  double* red = reinterpret_cast<double*>(smem);  // [2 (wm)][BN][2]
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int lcol = wn * (BN / 2) + j * 32 + l31;
+    const int col = n0 + lcol;
+    const bool cok = col < p.Nout;
+    const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        const int m = m0 + row;
+        if (m < p.M && cok) {
+          float v = acc[i][j][e] + bv;
+          if (p.add) v += p.add[(size_t)m * p.ldadd + col];
+          p.y[(size_t)m * p.ldy + col] = v;
+          const double dv = (double)v;
+          s1 += dv;
+          s2 += dv * dv;
+        }
+      }
+    }
+    if (p.stats) {
+      s1 += shfl_xor_f64(s1, 32);
+      s2 += shfl_xor_f64(s2, 32);
+      if (lhi == 0) {
+        red[(wm * BN + lcol) * 2 + 0] = s1;
+        red[(wm * BN + lcol) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    if (tid < BN) {
+      const int col = n0 + tid;
+      if (col < p.Nout) {
+        const double s1 = red[(0 * BN + tid) * 2 + 0] + red[(1 * BN + tid) * 2 + 0];
+        const double s2 = red[(0 * BN + tid) * 2 + 1] + red[(1 * BN + tid) * 2 + 1];
+        atomic_add_f64(&p.stats[col], s1);
+        atomic_add_f64(&p.stats[p.Nout + col], s2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: dW[co][tap][ci] = sum_m dy[m][co] * x[pix(m,tap)][ci]   (K = pixels)
+// One workgroup per (co tile, ci tile, tap, K split); partial sums go to a [ksplit] slab that
+// wgrad_reduce_unpack sums deterministically while converting to the OIHW layout of .grad.
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* dw;  // [ksplit][Co_pad][RS][Ci]
+  int ldx, lddy;
+  int N, Hin, Win, Ho, Wo;
+  int Ci, Co_pad;
+  int R, S, stride, pad, dil;
+  int M;      // N*Ho*Wo
+  int ksplit, kper;  // kper: pixels per split (multiple of 32)
+  int tiles_co, tiles_ci;
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+  constexpr int MREP = TM / 64, NREP = TN / 64;
+  constexpr int YV = TM / 4, XV = TN / 4;          // float4 per k-row
+  constexpr int Y_PER = 32 * YV / 256, X_PER = 32 * XV / 256;
+  constexpr int YROWS = 256 / YV, XROWS = 256 / XV;  // k-rows covered per pass
+  __shared__ __attribute__((aligned(16))) float smem[32 * (TM + TN)];
+  float* Ys = smem;            // [32][TM]
+  float* Xs = smem + 32 * TM;  // [32][TN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int RS = p.R * p.S;
+  int b = blockIdx.x;
+  const int tci = b % p.tiles_ci; b /= p.tiles_ci;
+  const int tco = b % p.tiles_co; b /= p.tiles_co;
+  const int tap = b % RS;
+  const int ks = b / RS;
+  const int r = tap / p.S, s = tap - r * p.S;
+  const int co0 = tco * TM, ci0 = tci * TN;
+  const int kbeg = ks * p.kper;
+  const int kend = min(p.M, kbeg + p.kper);
+
+  const int yc = tid % YV, yr = tid / YV;
+  const int xc = tid % XV, xr = tid / XV;
+  const int hw = p.Ho * p.Wo;
+
+  f32x4 ry[Y_PER], rx[X_PER];
+  auto prefetch = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < Y_PER; ++i) {
+      const int m = kb + yr + i * YROWS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < kend) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + co0 + yc * 4);
+      ry[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < X_PER; ++i) {
+      const int m = kb + xr + i * XROWS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < kend) {
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int oh = rem / p.Wo;
+        const int ow = rem - oh * p.Wo;
+        const int ih = oh * p.stride + r * p.dil - p.pad;
+        const int iw = ow * p.stride + s * p.dil - p.pad;
+        if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
+          v = *reinterpret_cast<const f32x4*>(
+              p.x + ((size_t)(n * p.Hin + ih) * p.Win + iw) * p.ldx + ci0 + xc * 4);
+      }
+      rx[i] = v;
+    }
+  };
+
+  f32x16 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (kbeg < kend) prefetch(kbeg);
+  for (int kb = kbeg; kb < kend; kb += 32) {
+#pragma unroll
+    for (int i = 0; i < Y_PER; ++i)
+      *reinterpret_cast<f32x4*>(&Ys[(yr + i * YROWS) * TM + yc * 4]) = ry[i];
+#pragma unroll
+    for (int i = 0; i < X_PER; ++i)
+      *reinterpret_cast<f32x4*>(&Xs[(xr + i * XROWS) * TN + xc * 4]) = rx[i];
+    __syncthreads();
+    if (kb + 32 < kend) prefetch(kb + 32);
+#pragma unroll
+    for (int kp = 0; kp < 16; ++kp) {
+      float a[MREP], bb[NREP];
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) a[i] = Ys[(2 * kp + lhi) * TM + wm * (TM / 2) + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) bb[j] = Xs[(2 * kp + lhi) * TN + wn * (TN / 2) + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float* out = p.dw + (size_t)ks * p.Co_pad * RS * p.Ci;
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int ci = ci0 + wn * (TN / 2) + j * 32 + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        if (co < p.Co_pad && ci < p.Ci) out[((size_t)co * RS + tap) * p.Ci + ci] = acc[i][j][e];
+      }
+    }
+}
+
+// dW partial slabs [ksplit][Co_pad][RS][Ci] -> OIHW gradient [Co][Ci][R][S] (sum over ksplit).
+__global__ void wgrad_reduce_unpack_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                           int ksplit, int Co, int Co_pad, int Ci, int RS,
+                                           int accumulate) {
+  const size_t total = (size_t)Co * Ci * RS;
+  const size_t slab = (size_t)Co_pad * RS * Ci;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(idx % RS);
+    const size_t t = idx / RS;
+    const int ci = (int)(t % Ci);
+    const int co = (int)(t / Ci);
+    const size_t src = ((size_t)co * RS + tap) * Ci + ci;
+    float v = 0.f;
+    for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * slab + src];
+    dw[idx] = accumulate ? dw[idx] + v : v;
+  }
+}
+
+// OIHW weights -> packed forward panel [Co_pad][KT*32], k = ((ci/32)*RS + tap)*32 + ci%32
+// (rows >= Co and channels >= Ci are zero).
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out, int Co,
+                                int Co_pad, int Ci, int Kc, int RS) {
+  const size_t total = (size_t)Co_pad * Kc * RS;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c32 = (int)(idx % 32);
+    size_t t = idx / 32;
+    const int tap = (int)(t % RS);
+    t /= RS;
+    const int chunk = (int)(t % (Kc / 32));
+    const int co = (int)(t / (Kc / 32));
+    const int ci = chunk * 32 + c32;
+    float v = 0.f;
+    if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * RS + tap];
+    out[idx] = v;
+  }
+}
+
+// OIHW weights -> packed dgrad panel [Ci_pad][KT*32] with K running over output channels:
+// k = ((co/32)*RS + tap)*32 + co%32.
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int Co,
+                                  int Kc, int Ci, int Ci_pad, int RS) {
+  const size_t total = (size_t)Ci_pad * Kc * RS;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c32 = (int)(idx % 32);
+    size_t t = idx / 32;
+    const int tap = (int)(t % RS);
+    t /= RS;
+    const int chunk = (int)(t % (Kc / 32));
+    const int ci = (int)(t / (Kc / 32));
+    const int co = chunk * 32 + c32;
+    float v = 0.f;
+    if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * RS + tap];
+    out[idx] = v;
+  }
+}
+
+inline int grid_for(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int semseg_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_dgrad, int Co, int Ci,
+                             int R, int S, int Co_pad, int Ci_pad, hipStream_t stream) {
+  if (!w_oihw || Co <= 0 || Ci <= 0 || R <= 0 || S <= 0) return SEMSEG_EINVAL;
+  const int RS = R * S;
+  if (w_fwd) {
+    if (Ci % 32 != 0 || Co_pad < Co) return SEMSEG_EINVAL;
+    const size_t total = (size_t)Co_pad * Ci * RS;
+    pack_fwd_kernel<<<grid_for(total, 256), 256, 0, stream>>>(w_oihw, w_fwd, Co, Co_pad, Ci, Ci, RS);
+  }
+  if (w_dgrad) {
+    const int Kc = (Co + 31) / 32 * 32;
+    if (Ci_pad < Ci) return SEMSEG_EINVAL;
+    const size_t total = (size_t)Ci_pad * Kc * RS;
+    pack_dgrad_kernel<<<grid_for(total, 256), 256, 0, stream>>>(w_oihw, w_dgrad, Co, Kc, Ci, Ci_pad, RS);
+  }
+  return semseg_launch_status();
+}
+
+static int conv_launch(bool transposed, const ConvArgs& a, int BN, hipStream_t stream) {
+  const int tiles_m = (a.M + 127) / 128;
+  ConvArgs p = a;
+  if (BN == 128) {
+    p.tiles_n = (a.Nout + 127) / 128;
+    const int grid = tiles_m * p.tiles_n;
+    if (transposed)
+      conv_igemm_kernel<128, 128, true><<<grid, 256, 0, stream>>>(p);
+    else
+      conv_igemm_kernel<128, 128, false><<<grid, 256, 0, stream>>>(p);
+  } else {
+    p.tiles_n = (a.Nout + 63) / 64;
+    const int grid = tiles_m * p.tiles_n;
+    if (transposed)
+      conv_igemm_kernel<128, 64, true><<<grid, 256, 0, stream>>>(p);
+    else
+      conv_igemm_kernel<128, 64, false><<<grid, 256, 0, stream>>>(p);
+  }
+  return semseg_launch_status();
+}
+
+int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
+                    int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
+                    int dil, const float* bias, const float* add, int ldadd, double* stats,
+                    int tile_n, hipStream_t stream) {
+  if (!x || !w_fwd || !y || Ci % 32 != 0 || (ldx & 3) || (tile_n != 64 && tile_n != 128))
+    return SEMSEG_EINVAL;
+  ConvArgs a;
+  a.x = x; a.w = w_fwd; a.y = y; a.bias = bias; a.add = add; a.stats = stats;
+  a.ldx = ldx; a.ldy = ldy; a.ldadd = ldadd;
+  a.N = N; a.Hin = H; a.Win = W; a.Hout = Ho; a.Wout = Wo;
+  a.Kc = Ci; a.Nout = Co; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.M = N * Ho * Wo; a.tiles_n = 0;
+  return conv_launch(false, a, tile_n, stream);
+}
+
+int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
+                      int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                      int pad, int dil, const float* add, int ldadd, int tile_n,
+                      hipStream_t stream) {
+  if (!dy || !w_dgrad || !dx || (lddy & 3) || (tile_n != 64 && tile_n != 128)) return SEMSEG_EINVAL;
+  const int Kc = (Co + 31) / 32 * 32;
+  if (lddy < Kc) return SEMSEG_EINVAL;
+  ConvArgs a;
+  a.x = dy; a.w = w_dgrad; a.y = dx; a.bias = nullptr; a.add = add; a.stats = nullptr;
+  a.ldx = lddy; a.ldy = lddx; a.ldadd = ldadd;
+  a.N = N; a.Hin = Ho; a.Win = Wo; a.Hout = H; a.Wout = W;
+  a.Kc = Kc; a.Nout = Ci; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.M = N * H * W; a.tiles_n = 0;
+  return conv_launch(true, a, tile_n, stream);
+}
+
+int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
+                      float* scratch, size_t scratch_floats, int N, int H, int W, int Ci, int Ho,
+                      int Wo, int Co, int R, int S, int stride, int pad, int dil, int accumulate,
+                      hipStream_t stream) {
+  if (!x || !dy || !dw_oihw || !scratch || (ldx & 3) || (lddy & 3) || Ci % 64 != 0)
+    return SEMSEG_EINVAL;
+  const int RS = R * S;
+  const int M = N * Ho * Wo;
+  const bool big = (Ci % 128 == 0) && (Co >= 128);
+  const int TM = big ? 128 : 64, TN = big ? 128 : 64;
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.dw = scratch; a.ldx = ldx; a.lddy = lddy;
+  a.N = N; a.Hin = H; a.Win = W; a.Ho = Ho; a.Wo = Wo; a.Ci = Ci;
+  a.tiles_co = (Co + TM - 1) / TM;
+  a.tiles_ci = Ci / TN;
+  a.Co_pad = a.tiles_co * TM;
+  if (lddy < a.Co_pad) return SEMSEG_EINVAL;  // dy rows must be readable (zero padded) up to Co_pad
+  a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil; a.M = M;
+  const int tiles = a.tiles_co * a.tiles_ci * RS;
+  const int ksteps = (M + 31) / 32;
+  int ksplit = (1536 + tiles - 1) / tiles;
+  if (ksplit > ksteps / 8) ksplit = ksteps / 8;
+  if (ksplit < 1) ksplit = 1;
+  const size_t slab = (size_t)a.Co_pad * RS * Ci;
+  while (ksplit > 1 && slab * ksplit > scratch_floats) --ksplit;
+  if (slab * ksplit > scratch_floats) return SEMSEG_EINVAL;
+  a.kper = ((ksteps + ksplit - 1) / ksplit) * 32;
+  ksplit = (M + a.kper - 1) / a.kper;
+  a.ksplit = ksplit;
+  const int grid = tiles * ksplit;
+  if (big)
+    conv_wgrad_kernel<128, 128><<<grid, 256, 0, stream>>>(a);
+  else
+    conv_wgrad_kernel<64, 64><<<grid, 256, 0, stream>>>(a);
+  const size_t total = (size_t)Co * Ci * RS;
+  wgrad_reduce_unpack_kernel<<<grid_for(total, 256), 256, 0, stream>>>(scratch, dw_oihw, ksplit, Co,
+                                                                      a.Co_pad, Ci, RS, accumulate);
+  return semseg_launch_status();
+}
+
+size_t semseg_conv_wgrad_scratch_floats(int Ci, int Co, int R, int S) {
+  const bool big = (Ci % 128 == 0) && (Co >= 128);
+  const int TM = big ? 128 : 64;
+  const size_t Co_pad = (size_t)((Co + TM - 1) / TM) * TM;
+  return Co_pad * R * S * Ci;  // one slab; callers size the arena as slabs * desired ksplit
+}
+
+}  // extern "C"

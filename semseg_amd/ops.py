@@ -1,0 +1,223 @@
+"""Thin tensor-level wrappers over the C ABI (include/semseg_hip.h).  torch is used only for device
+memory and the current HIP stream.  Every wrapper raises on a non-zero return code; nothing here
+computes on the CPU."""
+import torch
+
+from ._lib import lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ck(rc, name):
+    if rc != 0:
+        raise HipError("%s failed with code %d" % (name, rc))
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32, "expected a CUDA fp32 tensor"
+
+
+def roundup(x, m):
+    return (x + m - 1) // m * m
+
+
+def conv_out(h, k, s, p, d):
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------
+class PackedConv:
+    """Device-side packed copies of one OIHW conv weight (fwd + dgrad panels)."""
+
+    def __init__(self, Co, Ci, R, S, device, need_dgrad=True):
+        self.Co, self.Ci, self.R, self.S = Co, Ci, R, S
+        self.tile_fwd = 128 if Co >= 128 else 64
+        self.tile_dgrad = 128 if Ci >= 128 else 64
+        self.Co_pad = roundup(Co, self.tile_fwd)
+        self.Ci_pad = roundup(Ci, self.tile_dgrad)
+        self.Kc_dgrad = roundup(Co, 32)
+        self.w_fwd = torch.empty(self.Co_pad * Ci * R * S, dtype=torch.float32, device=device)
+        self.w_dgrad = (torch.empty(self.Ci_pad * self.Kc_dgrad * R * S, dtype=torch.float32,
+                                    device=device) if need_dgrad else None)
+
+    def pack(self, w_oihw):
+        _f32(w_oihw)
+        assert w_oihw.is_contiguous() and tuple(w_oihw.shape) == (self.Co, self.Ci, self.R, self.S)
+        _ck(lib.semseg_conv_pack_weights(_p(w_oihw), _p(self.w_fwd), _p(self.w_dgrad), self.Co,
+                                         self.Ci, self.R, self.S, self.Co_pad, self.Ci_pad,
+                                         _stream()), "conv_pack_weights")
+
+
+def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None, ldadd=0, stats=None):
+    Ho = conv_out(H, pk.R, stride, pad, dil)
+    Wo = conv_out(W, pk.S, stride, pad, dil)
+    _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
+                            pk.R, pk.S, stride, pad, dil, _p(bias), _p(add), ldadd, _p(stats),
+                            pk.tile_fwd, _stream()), "conv_fwd")
+    return Ho, Wo
+
+
+def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldadd=0):
+    Ho = conv_out(H, pk.R, stride, pad, dil)
+    Wo = conv_out(W, pk.S, stride, pad, dil)
+    _ck(lib.semseg_conv_dgrad(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo,
+                              pk.Co, pk.R, pk.S, stride, pad, dil, _p(add), ldadd, pk.tile_dgrad,
+                              _stream()), "conv_dgrad")
+
+
+def wgrad_scratch_floats(Ci, Co, R, S):
+    return int(lib.semseg_conv_wgrad_scratch_floats(Ci, Co, R, S))
+
+
+def conv_wgrad(x, ldx, dy, lddy, dw, scratch, N, H, W, Ci, Co, R, S, stride, pad, dil,
+               accumulate=False):
+    Ho = conv_out(H, R, stride, pad, dil)
+    Wo = conv_out(W, S, stride, pad, dil)
+    _ck(lib.semseg_conv_wgrad(_p(x), ldx, _p(dy), lddy, _p(dw), _p(scratch), scratch.numel(), N, H,
+                              W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, int(accumulate), _stream()),
+        "conv_wgrad")
+
+
+def stem_conv_fwd(x_nchw, w, y, N, H, W):
+    _ck(lib.semseg_stem_conv_fwd(_p(x_nchw), _p(w), _p(y), N, H, W, w.shape[0], _stream()),
+        "stem_conv_fwd")
+
+
+def stem_conv_wgrad(x_nchw, dy, dw, N, H, W, accumulate=False):
+    _ck(lib.semseg_stem_conv_wgrad(_p(x_nchw), _p(dy), _p(dw), N, H, W, dw.shape[0], int(accumulate),
+                                   _stream()), "stem_conv_wgrad")
+
+
+# ---------------------------------------------------------------------------------------------
+# batch norm family
+# ---------------------------------------------------------------------------------------------
+def channel_stats(x, ldx, stats, M, C):
+    _ck(lib.semseg_channel_stats(_p(x), ldx, _p(stats), M, C, _stream()), "channel_stats")
+
+
+def bn_finalize(stats, count, gamma, beta, rm, rv, nbt, momentum, eps, mean, invstd, scale, shift, C):
+    _ck(lib.semseg_bn_finalize(_p(stats), float(count), _p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt),
+                               momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), C,
+                               _stream()), "bn_finalize")
+
+
+def bn_eval_params(gamma, beta, rm, rv, eps, scale, shift, C):
+    _ck(lib.semseg_bn_eval_params(_p(gamma), _p(beta), _p(rm), _p(rv), eps, _p(scale), _p(shift), C,
+                                  _stream()), "bn_eval_params")
+
+
+def bn_apply(y, ldy, scale, shift, out, ldout, M, C, HW, relu, y2=None, ldy2=0, scale2=None,
+             shift2=None, res=None, ldres=0, dropmask=None):
+    _ck(lib.semseg_bn_apply(_p(y), ldy, _p(scale), _p(shift), _p(y2), ldy2, _p(scale2), _p(shift2),
+                            _p(res), ldres, _p(dropmask), _p(out), ldout, M, C, HW, int(relu),
+                            _stream()), "bn_apply")
+
+
+def bn_bwd_reduce(dout, lddout, out, ldout, dropmask, HW, y, ldy, mean, invstd, g, ldg, sums, M, C):
+    _ck(lib.semseg_bn_bwd_reduce(_p(dout), lddout, _p(out), ldout, _p(dropmask), HW, _p(y), ldy,
+                                 _p(mean), _p(invstd), _p(g), ldg, _p(sums), M, C, _stream()),
+        "bn_bwd_reduce")
+
+
+def bn_bwd_apply(g, ldg, y, ldy, mean, invstd, gamma, sums, count, dy, lddy, M, C):
+    _ck(lib.semseg_bn_bwd_apply(_p(g), ldg, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(sums),
+                                float(count), _p(dy), lddy, M, C, _stream()), "bn_bwd_apply")
+
+
+def bn_param_grads(sums, dgamma, dbeta, C, accumulate=False):
+    _ck(lib.semseg_bn_param_grads(_p(sums), _p(dgamma), _p(dbeta), C, int(accumulate), _stream()),
+        "bn_param_grads")
+
+
+# ---------------------------------------------------------------------------------------------
+# spatial ops
+# ---------------------------------------------------------------------------------------------
+def maxpool_fwd(x, y, idx, N, H, W, C):
+    _ck(lib.semseg_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), N, H, W, C, _stream()), "maxpool_fwd")
+
+
+def maxpool_bwd(dy, idx, dx, N, H, W, C):
+    _ck(lib.semseg_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), N, H, W, C, _stream()), "maxpool_bwd")
+
+
+_bins_cache = {}
+
+
+def _bins(bins):
+    import ctypes
+    key = tuple(bins)
+    if key not in _bins_cache:
+        _bins_cache[key] = (ctypes.c_int * len(key))(*key)
+    return ctypes.addressof(_bins_cache[key])
+
+
+def adaptive_avgpool_fwd(x, ldx, y, bins, N, H, W, C):
+    _ck(lib.semseg_adaptive_avgpool_fwd(_p(x), ldx, _p(y), _bins(bins), len(bins), N, H, W, C,
+                                        _stream()), "adaptive_avgpool_fwd")
+
+
+def adaptive_avgpool_bwd(base, ldbase, dpool, dx, lddx, bins, N, H, W, C):
+    _ck(lib.semseg_adaptive_avgpool_bwd(_p(base), ldbase, _p(dpool), _p(dx), lddx, _bins(bins),
+                                        len(bins), N, H, W, C, _stream()), "adaptive_avgpool_bwd")
+
+
+def bilinear_fwd(x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C):
+    _ck(lib.semseg_bilinear_fwd(_p(x), ldx, _p(y), ldy, N, Hi, Wi, Ho, Wo, C, _stream()),
+        "bilinear_fwd")
+
+
+def bilinear_bwd(dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C):
+    _ck(lib.semseg_bilinear_bwd(_p(dy), lddy, _p(dx), lddx, N, Hi, Wi, Ho, Wo, C, _stream()),
+        "bilinear_bwd")
+
+
+def bilinear_nhwc_to_nchw(x, ldx, y, N, Hi, Wi, Ho, Wo, C):
+    _ck(lib.semseg_bilinear_nhwc_to_nchw(_p(x), ldx, _p(y), N, Hi, Wi, Ho, Wo, C, _stream()),
+        "bilinear_nhwc_to_nchw")
+
+
+# ---------------------------------------------------------------------------------------------
+# fused CE head, SGD, psamask
+# ---------------------------------------------------------------------------------------------
+def ce_head_fwd(scores, ld, label, lse, pred, acc2, loss, N, h, w, H, W, C, ignore_index):
+    assert label.dtype == torch.int64
+    _ck(lib.semseg_ce_head_fwd(_p(scores), ld, _p(label), _p(lse), _p(pred), _p(acc2), _p(loss), N, h,
+                               w, H, W, C, ignore_index, _stream()), "ce_head_fwd")
+
+
+def ce_head_bwd(scores, ld, label, lse, acc2, grad_loss, grad_mul, dscores, lddz, accumulate, N, h, w,
+                H, W, C, ignore_index):
+    _ck(lib.semseg_ce_head_bwd(_p(scores), ld, _p(label), _p(lse), _p(acc2), _p(grad_loss),
+                               float(grad_mul), _p(dscores), lddz, int(accumulate), N, h, w, H, W, C,
+                               ignore_index, _stream()), "ce_head_bwd")
+
+
+def sgd_step(w, g, mom, n, lr, momentum, weight_decay, grad_scale=1.0, first_step=False, lr_dev=None):
+    _ck(lib.semseg_sgd_step(_p(w), _p(g), _p(mom), n, float(lr), _p(lr_dev), momentum, weight_decay,
+                            grad_scale, int(first_step), _stream()), "sgd_step")
+
+
+def psamask_forward(psa_type, inp, out, num, fH, fW, mH, mW, hH, hW):
+    _f32(inp, out)
+    _ck(lib.semseg_psamask_forward(psa_type, _p(inp), _p(out), num, fH, fW, mH, mW, hH, hW, _stream()),
+        "psamask_forward")
+
+
+def psamask_backward(psa_type, gout, gin, num, fH, fW, mH, mW, hH, hW):
+    _f32(gout, gin)
+    _ck(lib.semseg_psamask_backward(psa_type, _p(gout), _p(gin), num, fH, fW, mH, mW, hH, hW,
+                                    _stream()), "psamask_backward")

@@ -1,0 +1,374 @@
+"""GPU parity of every C-ABI kernel against a plain torch CPU reference of the same op (fp64 where a
+tighter reference is useful).  Error metric: max|a-b| / max|b| (relative to the tensor's scale), the
+same normalisation BASELINE.json uses for the logits."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, Ci, Co, k, stride, pad, dil
+    (2, 17, 19, 64, 64, 3, 1, 1, 1),
+    (2, 15, 15, 64, 128, 1, 1, 0, 1),
+    (1, 20, 20, 128, 256, 3, 1, 2, 2),
+    (1, 23, 23, 256, 128, 3, 1, 4, 4),
+    (2, 21, 21, 128, 128, 3, 2, 1, 1),
+    (2, 21, 21, 256, 512, 1, 2, 0, 1),
+    (2, 9, 9, 512, 150, 1, 1, 0, 1),
+    (3, 7, 7, 2048, 512, 1, 1, 0, 1),
+    (1, 12, 12, 512, 64, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, report):
+    from semseg_amd import ops
+    N, H, W, Ci, Co, k, s, p, d = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (Ci * k * k) ** 0.5)
+    bias = torch.randn(Co, generator=g)
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, s, p, d)
+    Ho, Wo = y64.shape[2:]
+    dy = torch.randn(N, Co, Ho, Wo, generator=g)
+    y64.backward(dy.double())
+
+    pk = ops.PackedConv(Co, Ci, k, k, DEV)
+    wd = w.to(DEV)
+    pk.pack(wd)
+    # activations live in a wider buffer to exercise the channel stride
+    ldx = Ci + 64
+    xb = torch.zeros(N, H, W, ldx, device=DEV)
+    xb[..., 32:32 + Ci] = nhwc(x).to(DEV)
+    xv = xb[..., 32:]
+    ldy = ops.roundup(Co, 128) + 128
+    yb = torch.zeros(N, Ho, Wo, ldy, device=DEV)
+    stats = torch.zeros(2 * Co, dtype=torch.float64, device=DEV)
+    ops.conv_fwd(xv, ldx, pk, yb, ldy, N, H, W, s, p, d, stats=stats)
+    y = nchw(yb[..., :Co])
+    e_f = relerr(y, y64)
+    e_s1 = relerr(stats[:Co], y64.sum((0, 2, 3)))
+    e_s2 = relerr(stats[Co:], (y64 * y64).sum((0, 2, 3)))
+    assert float(yb[..., Co:].abs().max()) == 0.0
+
+    # bias + residual add epilogue
+    addb = torch.randn(N, Ho, Wo, Co, generator=g).to(DEV)
+    yb2 = torch.zeros(N, Ho, Wo, Co, device=DEV)
+    ops.conv_fwd(xv, ldx, pk, yb2, Co, N, H, W, s, p, d, bias=bias.to(DEV), add=addb, ldadd=Co)
+    ref2 = y64.detach() + bias.double().view(1, -1, 1, 1) + nchw(addb.cpu()).double()
+    e_b = relerr(nchw(yb2), ref2)
+
+    # dgrad: dy lives in a zero-padded buffer (ld >= roundup(Co, 128))
+    dyb = torch.zeros(N, Ho, Wo, ldy, device=DEV)
+    dyb[..., :Co] = nhwc(dy).to(DEV)
+    dxb = torch.zeros(N, H, W, Ci, device=DEV)
+    ops.conv_dgrad(dyb, ldy, pk, dxb, Ci, N, H, W, s, p, d)
+    e_d = relerr(nchw(dxb), x64.grad)
+
+    # wgrad
+    dw = torch.empty(Co, Ci, k, k, device=DEV)
+    scratch = torch.empty(ops.wgrad_scratch_floats(Ci, Co, k, k) * 4, device=DEV)
+    ops.conv_wgrad(xv, ldx, dyb, ldy, dw, scratch, N, H, W, Ci, Co, k, k, s, p, d)
+    e_w = relerr(dw, w64.grad)
+    report("conv %s fwd %.2e stats %.2e/%.2e bias+add %.2e dgrad %.2e wgrad %.2e"
+           % (case, e_f, e_s1, e_s2, e_b, e_d, e_w))
+    assert max(e_f, e_b, e_d, e_w) < 2e-5
+    assert max(e_s1, e_s2) < 1e-5
+
+
+def test_stem(report):
+    from semseg_amd import ops
+    N, H, W = 2, 41, 33
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    w64 = w.double().requires_grad_(True)
+    y64 = F.conv2d(x.double(), w64, None, 2, 1)
+    Ho, Wo = y64.shape[2:]
+    dy = torch.randn(N, 64, Ho, Wo, generator=g)
+    y64.backward(dy.double())
+    xd, wd = x.to(DEV), w.to(DEV)
+    y = torch.empty(N, Ho, Wo, 64, device=DEV)
+    ops.stem_conv_fwd(xd, wd, y, N, H, W)
+    dw = torch.empty(64, 3, 3, 3, device=DEV)
+    ops.stem_conv_wgrad(xd, nhwc(dy).to(DEV), dw, N, H, W)
+    e1, e2 = relerr(nchw(y), y64), relerr(dw, w64.grad)
+    report("stem fwd %.2e wgrad %.2e" % (e1, e2))
+    assert e1 < 1e-5 and e2 < 1e-4
+
+
+@pytest.mark.parametrize("C,HW,mode", [(64, 13, "plain"), (256, 9, "res"), (1024, 5, "ds"),
+                                       (512, 6, "drop"), (2048, 3, "plain")])
+def test_bn_train_fwd_bwd(C, HW, mode, report):
+    from semseg_amd import ops
+    N = 3
+    M = N * HW * HW
+    g = torch.Generator().manual_seed(C + HW)
+    y = (torch.randn(N, C, HW, HW, generator=g) * 3 + 1.5).double().requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).double().requires_grad_(True)
+    beta = torch.randn(C, generator=g).double().requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g).double(), (torch.rand(C, generator=g) + 0.5).double()
+    rm0, rv0 = rm.clone(), rv.clone()
+    out = F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    extra = {}
+    if mode == "res":
+        res = torch.randn(N, C, HW, HW, generator=g).double().requires_grad_(True)
+        out = out + res
+        extra["res"] = res
+    if mode == "ds":
+        y2 = torch.randn(N, C, HW, HW, generator=g).double().requires_grad_(True)
+        g2 = (torch.rand(C, generator=g) + 0.5).double().requires_grad_(True)
+        b2 = torch.randn(C, generator=g).double().requires_grad_(True)
+        out = out + F.batch_norm(y2, None, None, g2, b2, True, 0.1, 1e-5)
+    out = F.relu(out)
+    dm = None
+    if mode == "drop":
+        dm = (torch.rand(N, C, generator=g) > 0.3).double() / 0.7
+        out = out * dm.view(N, C, 1, 1)
+    dout = torch.randn(N, C, HW, HW, generator=g).double()
+    out.backward(dout)
+
+    f = lambda t: t.detach().float().to(DEV)
+    yd = nhwc(f(y))
+    stats = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    ops.channel_stats(yd, C, stats, M, C)
+    mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
+    rmd, rvd = f(rm0), f(rv0)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    ops.bn_finalize(stats, M, f(gamma), f(beta), rmd, rvd, nbt, 0.1, 1e-5, mean, invstd, scale, shift, C)
+    outd = torch.empty(N, HW, HW, C, device=DEV)
+    kw = {}
+    if mode == "res":
+        kw = dict(res=nhwc(f(extra["res"])), ldres=C)
+    if mode == "ds":
+        y2d = nhwc(f(y2))
+        st2 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+        ops.channel_stats(y2d, C, st2, M, C)
+        mean2, invstd2, scale2, shift2 = (torch.empty(C, device=DEV) for _ in range(4))
+        ops.bn_finalize(st2, M, f(g2), f(b2), None, None, None, 0.1, 1e-5, mean2, invstd2, scale2, shift2, C)
+        kw = dict(y2=y2d, ldy2=C, scale2=scale2, shift2=shift2)
+    dmd = f(dm) if dm is not None else None
+    ops.bn_apply(yd, C, scale, shift, outd, C, M, C, HW * HW, True, dropmask=dmd, **kw)
+    e_out = relerr(nchw(outd), out)
+    e_rm, e_rv = relerr(rmd, rm), relerr(rvd, rv)
+    assert int(nbt.item()) == 1
+    # backward
+    doutd = nhwc(f(dout))
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    gd = torch.empty(N, HW, HW, C, device=DEV)
+    ops.bn_bwd_reduce(doutd, C, outd, C, dmd, HW * HW, yd, C, mean, invstd, gd, C, sums, M, C)
+    dyd = torch.empty(N, HW, HW, C, device=DEV)
+    ops.bn_bwd_apply(gd, C, yd, C, mean, invstd, f(gamma), sums, M, dyd, C, M, C)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_param_grads(sums, dg, db, C)
+    e_dy, e_dg, e_db = relerr(nchw(dyd), y.grad), relerr(dg, gamma.grad), relerr(db, beta.grad)
+    errs = [e_out, e_rm, e_rv, e_dy, e_dg, e_db]
+    if mode == "res":
+        errs.append(relerr(nchw(gd), extra["res"].grad))
+    if mode == "ds":
+        s2 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+        ops.bn_bwd_reduce(gd, C, None, 0, None, HW * HW, y2d, C, mean2, invstd2, None, 0, s2, M, C)
+        dy2 = torch.empty(N, HW, HW, C, device=DEV)
+        ops.bn_bwd_apply(gd, C, y2d, C, mean2, invstd2, f(g2), s2, M, dy2, C, M, C)
+        errs.append(relerr(nchw(dy2), y2.grad))
+    report("bn C=%d HW=%d %s: %s" % (C, HW, mode, " ".join("%.2e" % e for e in errs)))
+    assert max(errs) < 2e-5
+
+
+def test_bn_eval(report):
+    from semseg_amd import ops
+    C, N, HW = 128, 2, 7
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(N, C, HW, HW, generator=g)
+    gamma, beta, rm = torch.rand(C, generator=g) + .5, torch.randn(C, generator=g), torch.randn(C, generator=g)
+    rv = torch.rand(C, generator=g) + .5
+    ref = F.relu(F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5))
+    scale, shift = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_eval_params(gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5, scale, shift, C)
+    out = torch.empty(N, HW, HW, C, device=DEV)
+    ops.bn_apply(nhwc(y).to(DEV), C, scale, shift, out, C, N * HW * HW, C, HW * HW, True)
+    e = relerr(nchw(out), ref)
+    report("bn eval %.2e" % e)
+    assert e < 1e-5
+
+
+def test_maxpool(report):
+    from semseg_amd import ops
+    N, C, H, W = 2, 128, 23, 17
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, W, generator=g).double().requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g).double()
+    y.backward(dy)
+    Ho, Wo = y.shape[2:]
+    xd = nhwc(x.detach().float()).to(DEV)
+    yd = torch.empty(N, Ho, Wo, C, device=DEV)
+    idx = torch.empty(N, Ho, Wo, C // 4, dtype=torch.int32, device=DEV)
+    ops.maxpool_fwd(xd, yd, idx, N, H, W, C)
+    dx = torch.empty(N, H, W, C, device=DEV)
+    ops.maxpool_bwd(nhwc(dy.float()).to(DEV), idx, dx, N, H, W, C)
+    e1, e2 = relerr(nchw(yd), y), relerr(nchw(dx), x.grad)
+    report("maxpool fwd %.2e bwd %.2e" % (e1, e2))
+    assert e1 == 0.0 and e2 < 1e-6
+
+
+@pytest.mark.parametrize("H", [60, 10, 59])
+def test_adaptive_pool(H, report):
+    from semseg_amd import ops
+    N, C, W = 2, 2048, H - 1 if H > 20 else H
+    bins = (1, 2, 3, 6)
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(N, C, H, W, generator=g).double().requires_grad_(True)
+    outs = [F.adaptive_avg_pool2d(x, b) for b in bins]
+    dps = [torch.randn(o.shape, generator=g).double() for o in outs]
+    base = torch.randn(N, C, H, W, generator=g).double()
+    sum((o * d).sum() for o, d in zip(outs, dps)).backward()
+    ld = C + 512
+    xb = torch.zeros(N, H, W, ld, device=DEV)
+    xb[..., :C] = nhwc(x.detach().float()).to(DEV)
+    tot = sum(N * b * b * C for b in bins)
+    y = torch.empty(tot, device=DEV)
+    ops.adaptive_avgpool_fwd(xb, ld, y, bins, N, H, W, C)
+    off, es = 0, []
+    for b, o in zip(bins, outs):
+        n = N * b * b * C
+        es.append(relerr(nchw(y[off:off + n].view(N, b, b, C)), o))
+        off += n
+    dp = torch.cat([nhwc(d.float()).reshape(-1) for d in dps]).to(DEV)
+    dx = torch.empty(N, H, W, C, device=DEV)
+    ops.adaptive_avgpool_bwd(nhwc(base.float()).to(DEV), C, dp, dx, C, bins, N, H, W, C)
+    e_b = relerr(nchw(dx), x.grad + base)
+    report("adaptive pool H=%d fwd %s bwd %.2e" % (H, ["%.1e" % e for e in es], e_b))
+    assert max(es) < 1e-5 and e_b < 1e-5
+
+
+@pytest.mark.parametrize("hi,ho", [(1, 60), (2, 60), (3, 10), (6, 60), (30, 59), (59, 30)])
+def test_bilinear(hi, ho, report):
+    from semseg_amd import ops
+    N, C = 2, 512
+    wi, wo = hi, ho + (1 if ho > 20 else 0)
+    g = torch.Generator().manual_seed(hi * 100 + ho)
+    x = torch.randn(N, C, hi, wi, generator=g).double().requires_grad_(True)
+    y = F.interpolate(x, (ho, wo), mode="bilinear", align_corners=True)
+    dy = torch.randn(y.shape, generator=g).double()
+    y.backward(dy)
+    ldy = 2 * C
+    yb = torch.zeros(N, ho, wo, ldy, device=DEV)
+    ops.bilinear_fwd(nhwc(x.detach().float()).to(DEV), C, yb[..., C:], ldy, N, hi, wi, ho, wo, C)
+    dyb = torch.zeros(N, ho, wo, ldy, device=DEV)
+    dyb[..., C:] = nhwc(dy.float()).to(DEV)
+    dx = torch.empty(N, hi, wi, C, device=DEV)
+    ops.bilinear_bwd(dyb[..., C:], ldy, dx, C, N, hi, wi, ho, wo, C)
+    e1, e2 = relerr(nchw(yb[..., C:]), y), relerr(nchw(dx), x.grad)
+    report("bilinear %d->%d fwd %.2e bwd %.2e" % (hi, ho, e1, e2))
+    assert e1 < 1e-5 and e2 < 1e-5 and float(yb[..., :C].abs().max()) == 0
+
+
+@pytest.mark.parametrize("C,h,H", [(150, 9, 65), (19, 12, 89), (21, 5, 33)])
+def test_ce_head(C, h, H, report):
+    from semseg_amd import ops
+    N, w, W = 2, h + 1, None
+    W = (w - 1) * 8 + 1
+    ld = ops.roundup(C, 64) if C > 64 else 64
+    g = torch.Generator().manual_seed(C)
+    z = (torch.randn(N, C, h, w, generator=g) * 3).double().requires_grad_(True)
+    lab = torch.randint(0, C, (N, H, W), generator=g)
+    lab[torch.rand(N, H, W, generator=g) < 0.1] = 255
+    up = F.interpolate(z, (H, W), mode="bilinear", align_corners=True)
+    loss = F.cross_entropy(up, lab, ignore_index=255)
+    (loss * 0.4).backward()
+    zb = torch.zeros(N, h, w, ld, device=DEV)
+    zb[..., :C] = nhwc(z.detach().float()).to(DEV)
+    labd = lab.to(DEV)
+    lse = torch.empty(N, H, W, device=DEV)
+    pred = torch.empty(N, H, W, dtype=torch.int64, device=DEV)
+    acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+    lossd = torch.empty(1, device=DEV)
+    ops.ce_head_fwd(zb, ld, labd, lse, pred, acc, lossd, N, h, w, H, W, C, 255)
+    dz = torch.full((N, h, w, ld), 7.0, device=DEV)
+    gl = torch.tensor([0.4], device=DEV)
+    ops.ce_head_bwd(zb, ld, labd, lse, acc, gl, 1.0, dz, ld, False, N, h, w, H, W, C, 255)
+    e_l = abs(float(lossd.item()) - float(loss)) / abs(float(loss))
+    e_g = relerr(nchw(dz[..., :C]), z.grad)
+    agree = float((pred.cpu() == up.argmax(1)).float().mean())
+    padz = float(dz[..., C:ops.roundup(C, 4)].abs().max()) if ops.roundup(C, 4) > C else 0.0
+    report("ce head C=%d loss %.2e grad %.2e argmax-agree %.5f cnt %d/%d" %
+           (C, e_l, e_g, agree, int(acc[1].item()), int((lab != 255).sum())))
+    assert e_l < 1e-5 and e_g < 2e-5 and agree > 0.999 and padz == 0.0
+    assert int(acc[1].item()) == int((lab != 255).sum())
+
+
+def test_upsample_nchw(report):
+    from semseg_amd import ops
+    N, C, h, w, H, W = 2, 150, 9, 10, 65, 73
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(N, C, h, w, generator=g)
+    ref = F.interpolate(z, (H, W), mode="bilinear", align_corners=True)
+    zb = torch.zeros(N, h, w, 192, device=DEV)
+    zb[..., :C] = nhwc(z).to(DEV)
+    out = torch.empty(N, C, H, W, device=DEV)
+    ops.bilinear_nhwc_to_nchw(zb, 192, out, N, h, w, H, W, C)
+    e = relerr(out, ref)
+    report("upsample->nchw %.2e" % e)
+    assert e < 1e-5
+
+
+def test_sgd(report):
+    from semseg_amd import ops
+    n = 100003
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(n, generator=g)
+    p = torch.nn.Parameter(w.clone())
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    wd, mom = w.to(DEV), torch.zeros(n, device=DEV)
+    for it in range(3):
+        gr = torch.randn(n, generator=g)
+        p.grad = gr.clone()
+        opt.step()
+        ops.sgd_step(wd, gr.to(DEV), mom, n, 0.01, 0.9, 1e-4, 1.0, it == 0)
+    e = relerr(wd, p.data)
+    report("sgd %.2e" % e)
+    assert e < 1e-6
+
+
+@pytest.mark.parametrize("H,W,mH,mW", [(5, 5, 9, 9), (5, 7, 9, 13), (6, 6, 5, 5), (4, 4, 3, 3),
+                                      (30, 30, 59, 59)])
+def test_psamask_vs_oracle(H, W, mH, mW, report):
+    """Bit-exact against the C oracle (restatement of lib/psa/src/cpu/psamask.cpp)."""
+    import numpy as np
+    from oracle import psamask as orc
+    from semseg_amd import ops
+    N = 2
+    rng = np.random.default_rng(H * 1000 + mW)
+    x = rng.standard_normal((N, mH * mW, H, W)).astype(np.float32)
+    gy = rng.standard_normal((N, H * W, H, W)).astype(np.float32)
+    for t in (0, 1):
+        ref_f = orc.psa_mask_forward(x, t, mH, mW)
+        ref_b = orc.psa_mask_backward(gy, t, mH, mW)
+        out = torch.zeros(N, H * W, H, W, device=DEV)
+        ops.psamask_forward(t, torch.from_numpy(x).to(DEV), out, N, H, W, mH, mW, (mH - 1) // 2, (mW - 1) // 2)
+        gin = torch.zeros(N, mH * mW, H, W, device=DEV)
+        ops.psamask_backward(t, torch.from_numpy(gy).to(DEV), gin, N, H, W, mH, mW, (mH - 1) // 2, (mW - 1) // 2)
+        assert np.array_equal(out.cpu().numpy(), ref_f), "psamask fwd type %d" % t
+        assert np.array_equal(gin.cpu().numpy(), ref_b), "psamask bwd type %d" % t
+    report("psamask H=%d W=%d mask %dx%d bit-exact" % (H, W, mH, mW))
