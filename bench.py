@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the PSPNet-101 train step (473x473, global batch 16, 150 classes, fp32)
+on N MI355X GPUs of one node, the metric BASELINE.json names.
+
+One "step" = the loop body of the reference's tool/train.py:269-276 on a synthetic batch that is
+already resident in HBM: forward (SyncBN), loss = main + 0.4*aux, backward, gradient all-reduce
+(N>1), SGD(momentum 0.9, wd 1e-4, two lr groups).  Launch for N>1:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def conv_flops_per_image(model, size):
+    """Algorithmic conv FLOPs (2*MAC) of one forward, per image (477.4 GF for PSPNet101)."""
+    from semseg_amd.ops import conv_out
+    import torch.nn as nn
+    # spatial size seen by each conv: replay the stride structure of the trunk
+    total = 0
+    s = size
+    hw = {}
+    l0 = model.layer0
+    s0 = conv_out(s, 3, 2, 1, 1)
+    hw[l0[0]] = (s, s0)
+    hw[l0[3]] = (s0, s0)
+    hw[l0[6]] = (s0, s0)
+    sp = conv_out(s0, 3, 2, 1, 1)
+    cur = sp
+    for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
+        for blk in layer:
+            st = blk.conv2.stride[0]
+            out = conv_out(cur, 3, st, blk.conv2.padding[0], blk.conv2.dilation[0])
+            hw[blk.conv1] = (cur, cur)
+            hw[blk.conv2] = (cur, out)
+            hw[blk.conv3] = (out, out)
+            if blk.downsample is not None:
+                hw[blk.downsample[0]] = (cur, out)
+            cur = out
+    feat = cur
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d) and m not in hw:
+            hw[m] = (feat, feat)
+    if hasattr(model, "ppm"):
+        for f in model.ppm.features:
+            b = f[0].output_size
+            b = b if isinstance(b, int) else b[0]
+            hw[f[1]] = (b, b)
+    for m, (_, o) in hw.items():
+        co, ci, r, s_ = m.weight.shape
+        total += 2.0 * o * o * co * ci * r * s_
+    first = 2.0 * s0 * s0 * 64 * 3 * 9
+    return total, first
+
+
+def cpu_baseline(layers, classes, size, iters=2):
+    """The reference's arithmetic on the host cores: oracle/segnet.py (bit-identical to the imported
+    reference, see tests/golden/make_golden.py) forward + backward + SGD, batch 2."""
+    from oracle import segnet
+    from model.pspnet import PSPNet
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = PSPNet(layers=layers, classes=classes, zoom_factor=8, pretrained=False)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    opt = torch.optim.SGD(list(params.values()), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    B = 2
+    x = torch.randn(B, 3, size, size)
+    y = torch.randint(0, classes, (B, size, size))
+    times = []
+    for it in range(iters + 1):
+        t0 = time.time()
+        _, ml, al = segnet.forward(sd, x, layers, "psp", training=True, y=y)
+        loss = ml + 0.4 * al
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+    t = sum(times[1:]) / iters
+    return {"value": round(B / t, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "PSPNet%d %dx%d train step (fwd+bwd+SGD) batch %d, %d timed iterations after 1 warm-up, "
+                      "torch CPU fp32 via oracle/segnet.py" % (layers, size, size, B, iters)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=101)
+    ap.add_argument("--size", type=int, default=473)
+    ap.add_argument("--classes", type=int, default=150)
+    ap.add_argument("--global-batch", type=int, default=16)
+    ap.add_argument("--arch", default="psp")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    assert args.global_batch % world == 0
+    B = args.global_batch // world
+
+    from semseg_amd.trainer import Trainer, poly_learning_rate
+    from semseg_amd import engine as E
+    torch.manual_seed(0)  # identical initial weights on every rank (what DDP's broadcast achieves)
+    if args.arch == "psp":
+        from model.pspnet import PSPNet
+        model = PSPNet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
+    else:
+        from model.psanet import PSANet
+        model = PSANet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
+    fwd_flops, first_flops = conv_flops_per_image(model, args.size) if args.arch == "psp" else (0.0, 0.0)
+    model = model.to(dev).train()
+    tr = Trainer(model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, aux_weight=0.4, sync_bn=True)
+
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(B, 3, args.size, args.size, generator=g).to(dev)
+    y = torch.randint(0, args.classes, (B, args.size, args.size), generator=g).to(dev)
+
+    max_iter = args.steps + args.warmup + 1
+    it = 0
+    for _ in range(args.warmup):
+        tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
+        it += 1
+    kt = None
+    if rank == 0 and not args.no_kernel_timing:
+        kt = E.KernelTimer()
+        for e in tr.engines.values():
+            e.ktimer = kt
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        _, main_loss, aux_loss = tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
+        it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(main_loss.item())
+
+    if rank == 0:
+        ips = args.global_batch * args.steps / dt
+        step_flops = (3.0 * fwd_flops - first_flops) * args.global_batch
+        out = {
+            "metric": "images/sec (train step) PSPNet-%d %dx%d bs=%d" % (args.layers, args.size, args.size,
+                                                                     args.global_batch),
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PS%sNet%d ADE20K-shape %dx%d, %d classes, global batch %d (per-GPU %d), "
+                                   "train step fwd+loss+bwd+SGD, SyncBN, random-init weights"
+                                   % ("P" if args.arch == "psp" else "A", args.layers, args.size, args.size,
+                                      args.classes, args.global_batch, B),
+                       "parallelism": "dp%d" % world},
+            "final_main_loss": round(loss_val, 5),
+            "algorithmic_tflop_per_step": round(step_flops / 1e12, 3),
+            "whole_step_frac_of_f32_mfma_peak": round(step_flops / (dt / args.steps) / 1e12 / world /
+                                                      PEAK_F32_MFMA_TFLOPS, 4),
+        }
+        if kt is not None:
+            out["roofline"] = kt.roofline(PEAK_F32_MFMA_TFLOPS)
+            out["kernel_families"] = kt.summary()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.layers, args.classes, args.size)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,588 @@
+"""Static-shape executor of the PSPNet / PSANet forward + backward on the HIP kernel library.
+
+The nn.Module tree (model/pspnet.py, model/psanet.py in this repo) only *holds parameters* under the
+reference's state-dict names; this engine walks that tree once per (batch, H, W, mode), owns every
+activation / gradient buffer (NHWC fp32, explicit channel stride), and issues the C-ABI kernels
+(include/semseg_hip.h) on the current HIP stream.  Forward appends backward closures to a tape; the
+backward pass replays it in reverse.  No torch compute op is on the path (torch = device memory,
+streams, RNG for the Dropout2d mask, torch.distributed for the SyncBN / gradient all-reduce).
+
+Reference call structure mirrored here: model/pspnet.py:80-105 (PSPNet.forward),
+model/resnet.py:74-94 (Bottleneck.forward), model/pspnet.py:21-26 (PPM.forward),
+model/psanet.py:53-98 (PSA.forward).
+"""
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import ops
+
+F32 = torch.float32
+F64 = torch.float64
+
+
+class KernelTimer:
+    """HIP-event timing of the matrix-core kernels on the stream they are launched on (torch's current
+    stream).  Families are named after the kernel template instantiation rocprofv3 reports."""
+
+    def __init__(self):
+        self.rec = []
+
+    def span(self, family, flops):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.rec.append((family, flops, s, e))
+        return s, e
+
+    def _collect(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for family, flops, s, e in self.rec:
+            d = fam.setdefault(family, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += flops
+            d[2] += s.elapsed_time(e) * 1e-3
+        return fam
+
+    def summary(self):
+        out = {}
+        for k, (n, fl, t) in sorted(self._collect().items(), key=lambda kv: -kv[1][2]):
+            out[k] = {"launches": n, "total_ms": round(t * 1e3, 3), "avg_us": round(t / n * 1e6, 2),
+                      "tflops": round(fl / t / 1e12, 2) if t > 0 else None}
+        return out
+
+    def roofline(self, peak_tflops):
+        fam = self._collect()
+        k, (n, fl, t) = max(fam.items(), key=lambda kv: kv[1][2])
+        ach = fl / t / 1e12
+        return {"kernel": k, "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tflops,
+                "unit": "TFLOP/s", "frac": round(ach / peak_tflops, 4), "traffic": None,
+                "launches": n, "avg_launch_us": round(t / n * 1e6, 2),
+                "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
+
+
+class Act:
+    """NHWC activation view: `data` starts at the first valid channel; `ld` = channel stride."""
+    __slots__ = ("data", "N", "H", "W", "C", "ld", "grad", "ginit", "name")
+
+    def __init__(self, data, N, H, W, C, ld, name=""):
+        self.data, self.N, self.H, self.W, self.C, self.ld = data, N, H, W, C, ld
+        self.grad = None
+        self.ginit = False
+        self.name = name
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+    def slice(self, c0, C):
+        a = Act(self.data[..., c0:], self.N, self.H, self.W, C, self.ld, self.name + "[%d:]" % c0)
+        return a
+
+
+class ConvL:
+    def __init__(self, mod, device, need_dgrad=True):
+        w = mod.weight
+        self.mod = mod
+        self.Co, self.Ci, self.R, self.S = w.shape
+        self.stride, self.pad, self.dil = mod.stride[0], mod.padding[0], mod.dilation[0]
+        self.pk = ops.PackedConv(self.Co, self.Ci, self.R, self.S, device, need_dgrad)
+        self.wgrad = None
+        self.bgrad = None
+
+
+class BNL:
+    def __init__(self, mod, eng):
+        self.mod = mod
+        self.C = mod.num_features
+        self.eps = float(mod.eps)
+        self.momentum = 0.1 if mod.momentum is None else float(mod.momentum)
+        C = self.C
+        self.stats = eng.alloc_f64(2 * C)
+        self.sums = eng.alloc_f64(2 * C)
+        v = torch.empty(4 * C, dtype=F32, device=eng.device)
+        self.mean, self.invstd, self.scale, self.shift = v[:C], v[C:2 * C], v[2 * C:3 * C], v[3 * C:]
+        self.ggrad = None
+        self.bgrad = None
+
+
+class Engine:
+    def __init__(self, model, N, H, W, training, kind):
+        self.model = model
+        self.kind = kind  # "psp" | "psa"
+        self.N, self.H, self.W = N, H, W
+        self.training = training
+        self.device = next(model.parameters()).device
+        assert self.device.type == "cuda", "the HIP engine needs the model on an MI355X (cuda) device"
+        self._f64_chunks = []
+        self._bufs = {}
+        self._seq = 0
+        self.tape = []
+        self.convs = {}
+        self.bns = {}
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.sync_bn = self.world > 1 and any(isinstance(m, nn.SyncBatchNorm) for m in model.modules())
+        self.force_sync_bn = False
+        self._f64_arena = None
+        self._f64_off = 0
+        self._f64_cap = 0
+        self._register()
+        self._flat_grads()
+        self.wgrad_scratch = None
+        self.grads_ready_hook = None  # callable(param_list) fired as parameter gradients complete
+        self.weights_version = None
+        self.ktimer = None
+        self._mod_ids = tuple(id(m) for m in model.modules())
+
+    def params_stale(self):
+        """True when the module tree changed under us (convert_sync_batchnorm, .to(device), ...)."""
+        if tuple(id(m) for m in self.model.modules()) != self._mod_ids:
+            return True
+        p = self.params[0]
+        return p.device != self.device
+
+    # ------------------------------------------------------------------ registration
+    def alloc_f64(self, n):
+        if self._f64_arena is None:
+            total = 0
+            for m in self.model.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    total += 4 * m.num_features
+            total += 4096
+            self._f64_arena = torch.zeros(total, dtype=F64, device=self.device)
+            self._f64_cap = total
+        assert self._f64_off + n <= self._f64_cap
+        v = self._f64_arena[self._f64_off:self._f64_off + n]
+        self._f64_off += n
+        return v
+
+    def _register(self):
+        first = self.model.layer0[0]
+        for name, m in self.model.named_modules():
+            if isinstance(m, nn.Conv2d):
+                if m is first:
+                    self.convs[m] = None  # stem: direct kernel, no packed panel
+                else:
+                    self.convs[m] = ConvL(m, self.device)
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+                self.bns[m] = BNL(m, self)
+
+    def _flat_grads(self):
+        params = [p for p in self.model.parameters()]
+        self.params = params
+        total = sum(((p.numel() + 3) // 4) * 4 for p in params)
+        self.flat_grad = torch.zeros(total, dtype=F32, device=self.device)
+        self.grad_views = {}
+        off = 0
+        for p in params:
+            n = p.numel()
+            self.grad_views[p] = self.flat_grad[off:off + n].view(p.shape)
+            off += ((n + 3) // 4) * 4
+        for m, cl in self.convs.items():
+            if cl is not None:
+                cl.wgrad = self.grad_views[m.weight]
+                cl.bgrad = self.grad_views[m.bias] if m.bias is not None else None
+        for m, bl in self.bns.items():
+            bl.ggrad = self.grad_views[m.weight]
+            bl.bgrad = self.grad_views[m.bias]
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, shape, dtype=F32, zero=False, tag=""):
+        key = (self._seq, tag)
+        self._seq += 1
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        assert tuple(t.shape) == tuple(shape)
+        return t
+
+    def act(self, N, H, W, C, ld=None, zero=False, tag=""):
+        ld = C if ld is None else ld
+        t = self.buf((N, H, W, ld), zero=zero or ld != C, tag=tag)
+        return Act(t, N, H, W, C, ld, tag)
+
+    def grad_of(self, a):
+        if a.grad is None:
+            a.grad = self.buf((a.N, a.H, a.W, a.ld), zero=a.ld != a.C, tag="g:" + a.name)
+        return a.grad
+
+    # ------------------------------------------------------------------ weights
+    def pack_weights(self):
+        for m, cl in self.convs.items():
+            if cl is not None:
+                cl.pk.pack(m.weight.detach())
+
+    def _weights_sig(self):
+        return tuple(p._version for p in self.params) + tuple(p.data_ptr() for p in self.params[:4])
+
+    # ------------------------------------------------------------------ primitive layers
+    def conv(self, x, m, stats=None, out=None, bias=False):
+        cl = self.convs[m]
+        Ho = ops.conv_out(x.H, cl.R, cl.stride, cl.pad, cl.dil)
+        Wo = ops.conv_out(x.W, cl.S, cl.stride, cl.pad, cl.dil)
+        assert x.C == cl.Ci, (x.C, cl.Ci)
+        if out is None:
+            ld = cl.Co if cl.Co % 64 == 0 else ops.roundup(cl.Co, 128)
+            out = self.act(x.N, Ho, Wo, cl.Co, ld=ld, tag="conv")
+        ev = self._t0("conv_igemm_kernel<128,%d,false>" % cl.pk.tile_fwd, 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
+        ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                     bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats)
+        self._t1(ev)
+        if self.training:
+            self.tape.append(lambda: self._conv_bwd(x, out, cl, m))
+        return out
+
+    def _conv_bwd(self, x, y, cl, m):
+        dy = y.grad
+        assert dy is not None
+        if self.wgrad_scratch is None:
+            self.wgrad_scratch = torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device)
+        flops = 2.0 * y.M * cl.Co * cl.Ci * cl.R * cl.S
+        big = cl.Ci % 128 == 0 and cl.Co >= 128
+        ev = self._t0("conv_wgrad_kernel<%d,%d>+reduce" % ((128, 128) if big else (64, 64)), flops)
+        ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, self.wgrad_scratch, x.N, x.H, x.W, cl.Ci,
+                       cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil)
+        self._t1(ev)
+        ready = [m.weight]
+        if m.bias is not None:
+            # bias gradient = per-channel sum of dy (fp64 reduction, then the [C] cast kernel)
+            C4 = ops.roundup(cl.Co, 4)
+            st = self._bias_stats(C4)
+            st.zero_()
+            ops.channel_stats(dy, y.ld, st, y.M, C4)
+            ops.bn_param_grads(st, self._dummy(C4), cl.bgrad, cl.Co)
+            ready.append(m.bias)
+        if x.name != "input":
+            gx = self.grad_of(x)
+            ev = self._t0("conv_igemm_kernel<128,%d,true>" % cl.pk.tile_dgrad, flops)
+            ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                           add=gx if x.ginit else None, ldadd=x.ld)
+            self._t1(ev)
+            x.ginit = True
+        self._ready(ready)
+
+    def _t0(self, family, flops):
+        if self.ktimer is None:
+            return None
+        s, e = self.ktimer.span(family, flops)
+        s.record()
+        return e
+
+    def _t1(self, ev):
+        if ev is not None:
+            ev.record()
+
+    def _bias_stats(self, C4):
+        if not hasattr(self, "_bstats"):
+            self._bstats = self.alloc_f64(2 * 1024)
+            self._bdummy = torch.empty(1024, dtype=F32, device=self.device)
+        return self._bstats[:2 * C4]
+
+    def _dummy(self, C4):
+        return self._bdummy
+
+    def _ready(self, plist):
+        if self.grads_ready_hook is not None:
+            self.grads_ready_hook(plist)
+
+    def _sync(self, t):
+        if (self.sync_bn or self.force_sync_bn) and self.world > 1:
+            dist.all_reduce(t)
+            return self.world
+        return 1
+
+    def bn_prepare(self, bm, count):
+        """stats -> scale/shift (train: batch statistics, SyncBN all-reduce; eval: running stats)."""
+        bl = self.bns[bm]
+        if self.training and bm.training:
+            mult = self._sync(bl.stats)
+            cnt = count * mult
+            if cnt <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input "
+                                 "size [%d values per channel]" % cnt)
+            track = bm.track_running_stats and bm.running_mean is not None
+            ops.bn_finalize(bl.stats, cnt, bm.weight.detach(), bm.bias.detach(),
+                            bm.running_mean if track else None, bm.running_var if track else None,
+                            bm.num_batches_tracked if track else None, bl.momentum, bl.eps, bl.mean,
+                            bl.invstd, bl.scale, bl.shift, bl.C)
+            return cnt
+        ops.bn_eval_params(bm.weight.detach(), bm.bias.detach(), bm.running_mean, bm.running_var, bl.eps,
+                           bl.scale, bl.shift, bl.C)
+        return 0
+
+    def bn_act(self, y, bm, relu=True, res=None, y2=None, bm2=None, dropmask=None, out=None):
+        """out = [relu](bn(y) (+ bn2(y2)) (+ res)) (* dropmask)   — model/resnet.py:76-92."""
+        bl = self.bns[bm]
+        cnt = self.bn_prepare(bm, y.M)
+        bl2 = None
+        if y2 is not None:
+            bl2 = self.bns[bm2]
+            self.bn_prepare(bm2, y2.M)
+        if out is None:
+            out = self.act(y.N, y.H, y.W, y.C, tag="bnact")
+        ops.bn_apply(y.data, y.ld, bl.scale, bl.shift, out.data, out.ld, y.M, y.C, y.H * y.W, relu,
+                     y2=None if y2 is None else y2.data, ldy2=0 if y2 is None else y2.ld,
+                     scale2=None if bl2 is None else bl2.scale, shift2=None if bl2 is None else bl2.shift,
+                     res=None if res is None else res.data, ldres=0 if res is None else res.ld,
+                     dropmask=dropmask)
+        if self.training:
+            self.tape.append(lambda: self._bn_act_bwd(y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt))
+        return out
+
+    def _bn_act_bwd(self, y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt):
+        dout = out.grad
+        assert dout is not None and out.ginit
+        gy = self.grad_of(y)
+        if res is not None:
+            assert not res.ginit
+            g, ldg = self.grad_of(res), res.ld
+            res.ginit = True
+        else:
+            g, ldg = gy, y.ld
+        ops.bn_bwd_reduce(dout, out.ld, out.data if relu else None, out.ld, dropmask, y.H * y.W, y.data,
+                          y.ld, bl.mean, bl.invstd, g, ldg, bl.sums, y.M, y.C)
+        if y2 is not None:
+            ops.bn_bwd_reduce(g, ldg, None, 0, None, y2.H * y2.W, y2.data, y2.ld, bl2.mean, bl2.invstd,
+                              None, 0, bl2.sums, y2.M, y2.C)
+            ops.bn_param_grads(bl2.sums, bl2.ggrad, bl2.bgrad, bl2.C)
+            self._sync(bl2.sums)
+            gy2 = self.grad_of(y2)
+            ops.bn_bwd_apply(g, ldg, y2.data, y2.ld, bl2.mean, bl2.invstd, bm2.weight.detach(), bl2.sums,
+                             cnt, gy2, y2.ld, y2.M, y2.C)
+            y2.ginit = True
+            self._ready([bm2.weight, bm2.bias])
+        ops.bn_param_grads(bl.sums, bl.ggrad, bl.bgrad, bl.C)
+        self._sync(bl.sums)
+        ops.bn_bwd_apply(g, ldg, y.data, y.ld, bl.mean, bl.invstd, bm.weight.detach(), bl.sums, cnt, gy,
+                         y.ld, y.M, y.C)
+        y.ginit = True
+        self._ready([bm.weight, bm.bias])
+
+    # ------------------------------------------------------------------ network pieces
+    def stem(self, x_nchw):
+        """layer0 = conv-bn-relu x3 + maxpool (model/resnet.py:106-115, model/pspnet.py:46)."""
+        l0 = self.model.layer0
+        N, _, H, W = x_nchw.shape
+        c0 = l0[0]
+        Ho, Wo = ops.conv_out(H, 3, 2, 1, 1), ops.conv_out(W, 3, 2, 1, 1)
+        y0 = self.act(N, Ho, Wo, 64, tag="stem0")
+        w0 = c0.weight.detach()
+        ops.stem_conv_fwd(x_nchw, w0, y0.data, N, H, W)
+        bl = self.bns[l0[1]]
+        if self.training and l0[1].training:
+            ops.channel_stats(y0.data, y0.ld, bl.stats, y0.M, 64)
+        if self.training:
+            def bwd():
+                ops.stem_conv_wgrad(x_nchw, y0.grad, self.grad_views[c0.weight], N, H, W)
+                self._ready([c0.weight])
+            self.tape.append(bwd)
+        a = self.bn_act(y0, l0[1])
+        a = self.bn_act(self.conv(a, l0[3], stats=self._st(l0[4])), l0[4])
+        a = self.bn_act(self.conv(a, l0[6], stats=self._st(l0[7])), l0[7])
+        # maxpool
+        Hp, Wp = ops.conv_out(a.H, 3, 2, 1, 1), ops.conv_out(a.W, 3, 2, 1, 1)
+        p = self.act(N, Hp, Wp, a.C, tag="pool")
+        idx = self.buf((N, Hp, Wp, a.C // 4), dtype=torch.int32, tag="poolidx")
+        ops.maxpool_fwd(a.data, p.data, idx, N, a.H, a.W, a.C)
+        if self.training:
+            def bwd_pool():
+                ga = self.grad_of(a)
+                ops.maxpool_bwd(p.grad, idx, ga, N, a.H, a.W, a.C)
+                a.ginit = True
+            self.tape.append(bwd_pool)
+        return p
+
+    def _st(self, bm):
+        return self.bns[bm].stats if (self.training and bm.training) else None
+
+    def bottleneck(self, x, blk, out=None):
+        a1 = self.bn_act(self.conv(x, blk.conv1, stats=self._st(blk.bn1)), blk.bn1)
+        a2 = self.bn_act(self.conv(a1, blk.conv2, stats=self._st(blk.bn2)), blk.bn2)
+        y3 = self.conv(a2, blk.conv3, stats=self._st(blk.bn3))
+        if blk.downsample is not None:
+            yd = self.conv(x, blk.downsample[0], stats=self._st(blk.downsample[1]))
+            return self.bn_act(y3, blk.bn3, y2=yd, bm2=blk.downsample[1], out=out)
+        return self.bn_act(y3, blk.bn3, res=x, out=out)
+
+    def trunk(self, x_nchw, cat_C):
+        """layer0..layer4; layer4's output lands in channels [0,2048) of the head's concat buffer."""
+        m = self.model
+        a = self.stem(x_nchw)
+        for blk in m.layer1:
+            a = self.bottleneck(a, blk)
+        for blk in m.layer2:
+            a = self.bottleneck(a, blk)
+        for blk in m.layer3:
+            a = self.bottleneck(a, blk)
+        x_tmp = a
+        blocks = list(m.layer4)
+        cat = None
+        for i, blk in enumerate(blocks):
+            if i == len(blocks) - 1 and cat_C > 2048:
+                cat = self.act(a.N, a.H, a.W, cat_C, tag="cat")
+                a = self.bottleneck(a, blk, out=cat.slice(0, 2048))
+            else:
+                a = self.bottleneck(a, blk)
+        return x_tmp, a, cat
+
+    def ppm(self, x4, cat):
+        """PPM (model/pspnet.py:8-26): pooled 1x1 conv-bn-relu branches upsampled into the concat."""
+        feats = self.model.ppm.features
+        bins = []
+        for f in feats:
+            b = f[0].output_size
+            bins.append(b if isinstance(b, int) else b[0])
+        bins = tuple(bins)
+        N, H, W, C = x4.N, x4.H, x4.W, x4.C
+        tot = sum(N * b * b * C for b in bins)
+        pooled = self.buf((tot,), tag="pooled")
+        ops.adaptive_avgpool_fwd(x4.data, x4.ld, pooled, bins, N, H, W, C)
+        off = 0
+        pacts = []
+        c0 = C
+        for f, b in zip(feats, bins):
+            n = N * b * b * C
+            pa = Act(pooled[off:off + n].view(N, b, b, C), N, b, b, C, C, "pooled%d" % b)
+            off += n
+            pacts.append(pa)
+            yb = self.conv(pa, f[1], stats=self._st(f[2]))
+            ab = self.bn_act(yb, f[2])
+            dst = cat.slice(c0, ab.C)
+            ops.bilinear_fwd(ab.data, ab.ld, dst.data, dst.ld, N, b, b, H, W, ab.C)
+            if self.training:
+                def bwd_up(ab=ab, c0=c0, b=b):
+                    gab = self.grad_of(ab)
+                    ops.bilinear_bwd(cat.grad[..., c0:], cat.ld, gab, ab.ld, N, b, b, H, W, ab.C)
+                    ab.ginit = True
+                self.tape.append(bwd_up)
+            c0 += ab.C
+        if self.training:
+            dpool = self.buf((tot,), tag="dpool")
+            o = 0
+            for pa, b in zip(pacts, bins):
+                n = N * b * b * C
+                pa.grad = dpool[o:o + n].view(N, b, b, C)
+                o += n
+
+            def bwd_pool():
+                # x4.grad aliases cat.grad[..., :C]; the pooled-branch gradients are added in place
+                gx = cat.grad
+                ops.adaptive_avgpool_bwd(gx, cat.ld, dpool, gx, cat.ld, bins, N, H, W, C)
+                x4.grad = gx
+                x4.ginit = True
+            # must run after every branch backward => insert *before* the branch ops on the tape
+            self._ppm_pool_bwd = bwd_pool
+        return cat
+
+    def head(self, x, seq, tag):
+        """cls / aux: conv3x3-bn-relu-dropout2d-conv1x1(+bias) (model/pspnet.py:64-78)."""
+        conv_a, bn_a, drop, conv_b = seq[0], seq[1], seq[3], seq[4]
+        y = self.conv(x, conv_a, stats=self._st(bn_a))
+        dm = None
+        if self.training and drop.training and drop.p > 0:
+            dm = self.buf((x.N, y.C), tag="dropmask")
+            dm.bernoulli_(1.0 - drop.p).mul_(1.0 / (1.0 - drop.p))
+        a = self.bn_act(y, bn_a, dropmask=dm)
+        ncls = conv_b.weight.shape[0]
+        out = self.act(x.N, x.H, x.W, ncls, ld=ops.roundup(ncls, 128), tag="scores" + tag)
+        return self.conv(a, conv_b, out=out, bias=True)
+
+    def ce(self, scores, label, H, W, ignore_index, want_pred, tag):
+        N = scores.N
+        lse = self.buf((N, H, W), tag="lse" + tag)
+        pred = self.buf((N, H, W), dtype=torch.int64, tag="pred" + tag) if want_pred else None
+        acc = self.buf((2,), dtype=F64, tag="acc" + tag)
+        loss = self.buf((1,), tag="loss" + tag)
+        ops.ce_head_fwd(scores.data, scores.ld, label, lse, pred, acc, loss, N, scores.H, scores.W, H, W,
+                        scores.C, ignore_index)
+        rec = dict(scores=scores, label=label, lse=lse, acc=acc, H=H, W=W, ignore=ignore_index)
+        return loss, pred, rec
+
+    def ce_bwd(self, rec, gloss):
+        s = rec["scores"]
+        g = self.grad_of(s)
+        ops.ce_head_bwd(s.data, s.ld, rec["label"], rec["lse"], rec["acc"], gloss, 1.0, g, s.ld, False,
+                        s.N, s.H, s.W, rec["H"], rec["W"], s.C, rec["ignore"])
+        s.ginit = True
+
+    # ------------------------------------------------------------------ whole-network passes
+    def out_hw(self):
+        z = self.model.zoom_factor
+        return int((self.H - 1) / 8 * z + 1), int((self.W - 1) / 8 * z + 1)
+
+    def _begin(self, x):
+        assert x.is_cuda and x.dtype == F32 and tuple(x.shape) == (self.N, 3, self.H, self.W)
+        self._seq = 0
+        self.tape = []
+        sig = self._weights_sig()
+        if self.training or sig != self.weights_version:
+            self.pack_weights()
+            self.weights_version = sig
+        if self.training:
+            self._f64_arena.zero_()
+        return x.contiguous()
+
+    def _features(self, x):
+        m = self.model
+        if self.kind == "psp":
+            use = m.use_ppm
+            x_tmp, a, cat = self.trunk(x, 4096 if use else 2048)
+            if use:
+                ppm_mark = len(self.tape)
+                feat = self.ppm(a, cat)
+                if self.training:
+                    self.tape.insert(ppm_mark, self._ppm_pool_bwd)
+            else:
+                feat = a
+        else:
+            from .psa_engine import psa_forward
+            x_tmp, a, cat = self.trunk(x, 4096 if m.use_psa else 2048)
+            feat = psa_forward(self, a, cat) if m.use_psa else a
+        return x_tmp, feat
+
+    def forward_eval(self, x):
+        x = self._begin(x)
+        x_tmp, feat = self._features(x)
+        scores = self.head(feat, self.model.cls, "m")
+        h, w = self.out_hw()
+        ncls = scores.C
+        if self.model.zoom_factor != 1:
+            out = torch.empty((self.N, ncls, h, w), dtype=F32, device=self.device)
+            ops.bilinear_nhwc_to_nchw(scores.data, scores.ld, out, self.N, scores.H, scores.W, h, w, ncls)
+        else:
+            out = torch.empty((self.N, ncls, h, w), dtype=F32, device=self.device)
+            ops.bilinear_nhwc_to_nchw(scores.data, scores.ld, out, self.N, scores.H, scores.W, scores.H,
+                                      scores.W, ncls)
+        return out
+
+    def forward_train(self, x, y, ignore_index=255):
+        x = self._begin(x)
+        self._x = Act(x, self.N, self.H, self.W, 3, 3, "input")
+        assert y.dtype == torch.int64 and y.is_cuda
+        y = y.contiguous()
+        h, w = self.out_hw()
+        assert tuple(y.shape) == (self.N, h, w), "target must be [N,%d,%d]" % (h, w)
+        x_tmp, feat = self._features(x)
+        scores = self.head(feat, self.model.cls, "m")
+        aux = self.head(x_tmp, self.model.aux, "a")
+        main_loss, pred, self._rec_main = self.ce(scores, y, h, w, ignore_index, True, "m")
+        aux_loss, _, self._rec_aux = self.ce(aux, y, h, w, ignore_index, False, "a")
+        return pred, main_loss, aux_loss
+
+    def backward(self, gmain, gaux):
+        """Replays the tape; on return every parameter gradient is in self.grad_views."""
+        for t in self._bufs.values():
+            pass
+        self._reset_grad_flags()
+        self._f64_zero_sums()
+        self.ce_bwd(self._rec_main, gmain)
+        self.ce_bwd(self._rec_aux, gaux)
+        for fn in reversed(self.tape):
+            fn()
+
+    def _reset_grad_flags(self):
+        pass  # Act objects are rebuilt every forward, so ginit starts False
+
+    def _f64_zero_sums(self):
+        # stats and sums share the arena; stats are dead after forward
+        self._f64_arena.zero_()

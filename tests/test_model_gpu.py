@@ -1,0 +1,177 @@
+"""End-to-end parity of the HIP PSPNet against the CPU oracle (oracle/segnet.py, pinned bit-exactly to
+the imported reference by tests/golden/make_golden.py) and against the committed golden fixtures.
+Tolerance: BASELINE.json north_star — max|logits - ref| / max|ref| <= 1e-3 (fp32); we assert 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def build(arch, layers, classes, **kw):
+    from oracle import segnet
+    if arch == "psp":
+        from model.pspnet import PSPNet
+        m = PSPNet(layers=layers, classes=classes, zoom_factor=8, dropout=0.0, pretrained=False, **kw)
+    else:
+        from model.psanet import PSANet
+        m = PSANet(layers=layers, classes=classes, zoom_factor=8, dropout=0.0, pretrained=False, **kw)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = segnet.recipe_state_dict(shapes, seed=1234)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+def inputs(batch, size, classes, zoom=8):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    hh = int((size - 1) / 8 * zoom + 1)
+    y = torch.randint(0, classes, (batch, hh, hh), generator=g)
+    y[torch.rand(batch, hh, hh, generator=g) < 0.05] = 255
+    return x, y
+
+
+def _oracle_train(sd, x, y, layers, arch, psa_cfg, dt):
+    from oracle import segnet
+    sd_t = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            v = v.clone().to(dt)
+            if "running" not in k:
+                v.requires_grad_(True)
+        else:
+            v = v.clone()
+        sd_t[k] = v
+    p, ml, al = segnet.forward(sd_t, x.to(dt), layers, arch, training=True, y=y, psa_cfg=psa_cfg)
+    (ml + 0.4 * al).backward()
+    return sd_t, p, ml, al
+
+
+def run_case(report, name, arch, layers, classes, size, batch, gold=None, psa_cfg=None):
+    """Gradient criterion: in fp32 the backward pass of this network is dominated by ReLU-mask flips
+    (an activation within ~1e-4 of zero changes sign between two fp32 implementations) and by train-mode
+    BatchNorm over few samples: the reference's own CPU fp32 gradients differ from an fp64 run of the
+    same graph by up to ~1e-1 on the 73^2 case.  So every gradient (HIP fp32 and reference-arithmetic CPU
+    fp32) is measured against the fp64 oracle and the two error distributions must agree (median, q90,
+    max within 2-4x); the per-kernel 1e-6 bounds live in tests/test_ops_gpu.py."""
+    from oracle import segnet
+    kw = dict(psa_cfg) if psa_cfg else {}
+    m, sd = build(arch, layers, classes, **kw)
+    x, y = inputs(batch, size, classes)
+    with torch.no_grad():
+        ref_logits = segnet.forward({k: v.clone() for k, v in sd.items()}, x, layers, arch, training=False,
+                                    psa_cfg=psa_cfg)
+    s32, p_ref, ml_ref, al_ref = _oracle_train(sd, x, y, layers, arch, psa_cfg, torch.float32)
+    s64, p64, ml64, al64 = _oracle_train(sd, x, y, layers, arch, psa_cfg, torch.float64)
+    # ---- HIP
+    m = m.cuda()
+    m.eval()
+    logits = m(x.cuda())
+    e_logit = rel(logits, ref_logits)
+    m.train()
+    pred, ml, al = m(x.cuda(), y.cuda())
+    (ml + 0.4 * al).backward()
+    e_ml = abs(ml.item() - ml64.item()) / abs(ml64.item())
+    e_al = abs(al.item() - al64.item()) / abs(al64.item())
+    agree = float((pred.cpu() == p_ref).float().mean())
+    rows = []
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        rows.append((rel(p.grad, s64[k].grad), rel(s32[k].grad, s64[k].grad), k))
+    eh = sorted(r[0] for r in rows)
+    ec = sorted(r[1] for r in rows)
+    q = lambda v, f: v[min(len(v) - 1, int(f * len(v)))]
+    worst = max(rows)
+    report("   grads vs fp64 oracle [hip | cpu-fp32]: median %.1e | %.1e, q90 %.1e | %.1e, max %.1e | %.1e (hip worst at %s); "
+           "head grads cls.4.weight %.1e aux.4.weight %.1e" %
+           (q(eh, .5), q(ec, .5), q(eh, .9), q(ec, .9), eh[-1], ec[-1], worst[2],
+            rel(m.cls[4].weight.grad, s64["cls.4.weight"].grad), rel(m.aux[4].weight.grad, s64["aux.4.weight"].grad)))
+    # statistical equivalence with the reference's own fp32 arithmetic (ReLU-mask flips dominate both)
+    bad = []
+    if q(eh, .5) > 2 * q(ec, .5) + 1e-5:
+        bad.append(("median", q(eh, .5), q(ec, .5)))
+    if q(eh, .9) > 2 * q(ec, .9) + 1e-5:
+        bad.append(("q90", q(eh, .9), q(ec, .9)))
+    if eh[-1] > max(4 * ec[-1], 1e-3):
+        bad.append(("max", eh[-1], ec[-1]))
+    # the last conv of each head sees no ReLU/BN noise of its own: tight check
+    for k in ("cls.4.bias", "aux.4.bias", "aux.4.weight"):
+        e = rel(dict(m.named_parameters())[k].grad, s64[k].grad)
+        if e > 2e-4:
+            bad.append((k, e))
+    new_sd = m.state_dict()
+    runs = sorted(((rel(new_sd[k], s64[k]), rel(s32[k], s64[k]), k) for k in new_sd if "running" in k), reverse=True)
+    bad_run = [(a, b, k) for a, b, k in runs if a > max(1e-4, 4 * b)]
+    nbt = int(new_sd["layer0.1.num_batches_tracked"])
+    report("%s: logits %.2e main %.2e aux %.2e argmax %.5f worst-running %.1e (cpu %.1e) nbt %d"
+           % (name, e_logit, e_ml, e_al, agree, runs[0][0], runs[0][1], nbt))
+    assert e_logit < 1e-4 and e_ml < 1e-5 and e_al < 1e-5 and agree > 0.999
+    assert not bad, bad[:5]
+    assert not bad_run, bad_run[:5]
+    assert nbt == 1
+    if gold:
+        fx = np.load(os.path.join(GOLD, gold))
+        smp = logits[:, ::7, ::5, ::5].cpu().numpy()
+        e = np.abs(smp - fx["logits_sample"]).max() / fx["logits_absmax"]
+        assert e < 1e-4, e
+        assert abs(ml.item() - fx["main_loss"]) / fx["main_loss"] < 1e-5
+        assert abs(al.item() - fx["aux_loss"]) / fx["aux_loss"] < 1e-5
+        assert float((pred[:, ::5, ::5].cpu().numpy() == fx["pred_sample"]).mean()) > 0.999
+        params = dict(m.named_parameters())
+        for k in ("cls.4.bias", "cls.4.weight", "aux.4.bias"):  # the well-conditioned gradients
+            gk = params[k].grad.cpu().numpy()
+            assert np.abs(gk - fx["grad/" + k]).max() / np.abs(fx["grad/" + k]).max() < 1e-3, k
+        for k in fx.files:
+            if k.startswith("buf/"):
+                assert np.abs(new_sd[k[4:]].cpu().numpy() - fx[k]).max() / np.abs(fx[k]).max() < 2e-4, k
+        report("%s: matches golden fixture %s (reference outputs)" % (name, gold))
+
+
+def test_pspnet50_small_vs_oracle_and_golden(report):
+    run_case(report, "pspnet50 c21 73^2 b2", "psp", 50, 21, 73, 2, gold="pspnet50_c21_s73_b2.npz")
+
+
+def test_pspnet50_ade_shape(report):
+    """configs[0]/[1] shape at CPU-affordable batch: PSPNet50, 150 classes, 473x473."""
+    run_case(report, "pspnet50 c150 473^2 b2", "psp", 50, 150, 473, 2)
+
+
+def test_pspnet101_logits(report):
+    """Metric model: PSPNet101 473^2 eval logits vs oracle."""
+    from oracle import segnet
+    m, sd = build("psp", 101, 150)
+    x, _ = inputs(1, 473, 150)
+    with torch.no_grad():
+        ref = segnet.forward({k: v.clone() for k, v in sd.items()}, x, 101, "psp", training=False)
+    m = m.cuda().eval()
+    out = m(x.cuda())
+    e = rel(out, ref)
+    report("pspnet101 c150 473^2 b1 eval logits %.2e (|ref|max %.3e)" % (e, float(ref.abs().max())))
+    assert e < 1e-4
+
+
+def test_second_step_reuses_buffers(report):
+    """Two consecutive train steps with an optimizer in between: engine buffers are reused, gradients
+    are fresh (no accumulation leaks)."""
+    m, sd = build("psp", 50, 21)
+    m = m.cuda().train()
+    x, y = inputs(2, 73, 21)
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    outs = []
+    for _ in range(2):
+        opt.zero_grad()
+        _, ml, al = m(x.cuda(), y.cuda())
+        (ml + 0.4 * al).backward()
+        outs.append((ml.item(), m.cls[4].weight.grad.clone(), m.layer0[0].weight.grad.clone()))
+        opt.step()
+    assert outs[0][0] == pytest.approx(outs[1][0], rel=1e-6)
+    assert rel(outs[1][1], outs[0][1]) < 1e-5 and rel(outs[1][2], outs[0][2]) < 1e-4
+    report("second step: losses and grads reproduce")
