@@ -121,6 +121,24 @@ int semseg_ce_head_bwd(const float* scores, int ld, const long long* label, cons
                        int lddz, int accumulate, int N, int h, int w, int H, int W, int C,
                        int ignore_index, hipStream_t stream);
 
+/* ---- PSA head on the engine's pixel-major layout (model/psanet.py:53-98).
+ * psamask_nhwc: attention map [N, H*W, taps(ldm)] <-> affinity rows aff[n, q, p] (lda >= H*W), same
+ * index maps as semseg_psamask_* (lib/psa/src/cpu/psamask.cpp:11-113); out-of-window entries = 0.
+ * softmax_rows: y = alpha*softmax(x[0:P)) per row (F.softmax(dim=1) + 1/normalization_factor,
+ * psanet.py:88-91); transpose_batched: out[b][c][r] = in[b][r][c], columns r >= R zero-filled. */
+int semseg_psamask_nhwc_forward(int psa_type, const float* mask, int ldm, float* aff, int lda, int N,
+                                int H, int W, int mH, int mW, hipStream_t stream);
+int semseg_psamask_nhwc_backward(int psa_type, const float* daff, int lda, float* dmask, int ldm,
+                                 int N, int H, int W, int mH, int mW, hipStream_t stream);
+int semseg_softmax_rows_fwd(const float* x, int ldx, float* y, int ldy, int rows, int P,
+                            float alpha, int softmax, hipStream_t stream);
+int semseg_softmax_rows_bwd(const float* y, int ldy, const float* dy, int lddy, float* dx,
+                            int lddx, int rows, int P, float alpha, int softmax,
+                            hipStream_t stream);
+int semseg_transpose_batched(const float* in, int ldi, long long batch_stride_in, float* out,
+                             int ldo, long long batch_stride_out, int batch, int R, int C,
+                             hipStream_t stream);
+
 /* ---- torch.optim.SGD step (tool/train.py:140,276) over a flat range. */
 int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, float lr, const float* lr_dev,
                     float momentum, float weight_decay, float grad_scale, int first_step,

@@ -75,6 +75,17 @@ def head(sd, x, p, training, dropmask=None):
     return F.conv2d(x, sd[p + ".4.weight"], sd[p + ".4.bias"])
 
 
+def _perm(fn, t, *a):
+    """The C oracle is fp32-only like the reference (psamask.cpp:117 `.data<float>()`); the op is a pure
+    permutation, so an fp64 tensor is moved as a hi/lo pair of fp32 parts (exact to ~1e-15)."""
+    if t.dtype == torch.float32:
+        return torch.from_numpy(fn(t.detach().contiguous().numpy(), *a))
+    hi = t.detach().float()
+    lo = (t.detach() - hi.double()).float()
+    return (torch.from_numpy(fn(hi.contiguous().numpy(), *a)).double() +
+            torch.from_numpy(fn(lo.contiguous().numpy(), *a)).double())
+
+
 class _PsaMask(torch.autograd.Function):
     """lib/psa/functions/psamask.py:6-39 on top of the C oracle (oracle/psamask_oracle.c)."""
 
@@ -82,13 +93,13 @@ class _PsaMask(torch.autograd.Function):
     def forward(ctx, inp, psa_type, mH, mW):
         from . import psamask as pm
         ctx.cfg = (psa_type, mH, mW)
-        return torch.from_numpy(pm.psa_mask_forward(inp.detach().numpy(), psa_type, mH, mW))
+        return _perm(pm.psa_mask_forward, inp, psa_type, mH, mW)
 
     @staticmethod
     def backward(ctx, g):
         from . import psamask as pm
         t, mH, mW = ctx.cfg
-        return torch.from_numpy(pm.psa_mask_backward(g.contiguous().numpy(), t, mH, mW)), None, None, None
+        return _perm(pm.psa_mask_backward, g, t, mH, mW), None, None, None
 
 
 def psa(sd, x, cfg, training):

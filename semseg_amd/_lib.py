@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libsemseg_hip.so")
 
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
-    "size_t": ctypes.c_size_t, "hipStream_t": ctypes.c_void_p,
+    "size_t": ctypes.c_size_t, "hipStream_t": ctypes.c_void_p, "long long": ctypes.c_longlong,
 }
 
 

@@ -221,3 +221,45 @@ def psamask_backward(psa_type, gout, gin, num, fH, fW, mH, mW, hH, hW):
     _f32(gout, gin)
     _ck(lib.semseg_psamask_backward(psa_type, _p(gout), _p(gin), num, fH, fW, mH, mW, hH, hW,
                                     _stream()), "psamask_backward")
+
+
+# ---------------------------------------------------------------------------------------------
+# PSA head (pixel-major layout) + raw GEMM entry points used for the point-affinity contraction
+# ---------------------------------------------------------------------------------------------
+def psamask_nhwc_forward(psa_type, mask, ldm, aff, lda, N, H, W, mH, mW):
+    _ck(lib.semseg_psamask_nhwc_forward(psa_type, _p(mask), ldm, _p(aff), lda, N, H, W, mH, mW, _stream()),
+        "psamask_nhwc_forward")
+
+
+def psamask_nhwc_backward(psa_type, daff, lda, dmask, ldm, N, H, W, mH, mW):
+    _ck(lib.semseg_psamask_nhwc_backward(psa_type, _p(daff), lda, _p(dmask), ldm, N, H, W, mH, mW,
+                                         _stream()), "psamask_nhwc_backward")
+
+
+def softmax_rows_fwd(x, ldx, y, ldy, rows, P, alpha, softmax):
+    _ck(lib.semseg_softmax_rows_fwd(_p(x), ldx, _p(y), ldy, rows, P, float(alpha), int(softmax),
+                                    _stream()), "softmax_rows_fwd")
+
+
+def softmax_rows_bwd(y, ldy, dy, lddy, dx, lddx, rows, P, alpha, softmax):
+    _ck(lib.semseg_softmax_rows_bwd(_p(y), ldy, _p(dy), lddy, _p(dx), lddx, rows, P, float(alpha),
+                                    int(softmax), _stream()), "softmax_rows_bwd")
+
+
+def transpose_batched(inp, ldi, bsi, out, ldo, bso, batch, R, C):
+    _ck(lib.semseg_transpose_batched(_p(inp), ldi, bsi, _p(out), ldo, bso, batch, R, C, _stream()),
+        "transpose_batched")
+
+
+def gemm_rows(a_ptr, lda, bt_ptr, c_ptr, ldc, M, K, Nout, add_ptr=None, ldadd=0):
+    """C[M][Nout] = A[M][K] * B, B given K-contiguous as bt[Nout_pad][K] (K % 32 == 0): the 1x1
+    implicit-GEMM kernel on raw device pointers."""
+    tile = 128 if Nout >= 128 else 64
+    _ck(lib.semseg_conv_fwd(a_ptr, lda, bt_ptr, c_ptr, ldc, 1, M, 1, K, M, 1, Nout, 1, 1, 1, 0, 1, None,
+                            add_ptr, ldadd, None, tile, _stream()), "gemm_rows")
+
+
+def gemm_kmajor(x_ptr, ldx, y_ptr, ldy, out_ptr, scratch, K, Ci, Co, accumulate=False):
+    """out[Co][Ci] (=|+=) sum_k y[k][co] * x[k][ci] — the weight-gradient kernel as a K-major GEMM."""
+    _ck(lib.semseg_conv_wgrad(x_ptr, ldx, y_ptr, ldy, out_ptr, _p(scratch), scratch.numel(), 1, K, 1, Ci,
+                              K, 1, Co, 1, 1, 1, 0, 1, int(accumulate), _stream()), "gemm_kmajor")

@@ -175,3 +175,21 @@ def test_second_step_reuses_buffers(report):
     assert outs[0][0] == pytest.approx(outs[1][0], rel=1e-6)
     assert rel(outs[1][1], outs[0][1]) < 1e-5 and rel(outs[1][2], outs[0][2]) < 1e-4
     report("second step: losses and grads reproduce")
+
+
+PSA_CFG = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=9, mask_w=9, normalization_factor=1.0,
+               psa_softmax=True)
+
+
+def test_psanet50_small_vs_oracle_and_golden(report):
+    """configs[3] path at CPU-affordable size: PSANet (psa_type 2, collect + distribute, shrink 2)."""
+    run_case(report, "psanet50 c19 65^2 b2", "psa", 50, 19, 65, 2, gold="psanet50_c19_s65_b2.npz", psa_cfg=PSA_CFG)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(psa_type=0, compact=False, shrink_factor=2, mask_h=5, mask_w=7, normalization_factor=2.0, psa_softmax=True),
+    dict(psa_type=1, compact=False, shrink_factor=1, mask_h=17, mask_w=17, normalization_factor=None, psa_softmax=False),
+    dict(psa_type=2, compact=True, shrink_factor=2, mask_h=5, mask_w=5, normalization_factor=1.0, psa_softmax=True),
+])
+def test_psanet_variants(cfg, report):
+    run_case(report, "psanet50 %s" % (cfg,), "psa", 50, 19, 65, 2, psa_cfg=cfg)

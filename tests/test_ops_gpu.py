@@ -372,3 +372,84 @@ def test_psamask_vs_oracle(H, W, mH, mW, report):
         assert np.array_equal(out.cpu().numpy(), ref_f), "psamask fwd type %d" % t
         assert np.array_equal(gin.cpu().numpy(), ref_b), "psamask bwd type %d" % t
     report("psamask H=%d W=%d mask %dx%d bit-exact" % (H, W, mH, mW))
+
+
+@pytest.mark.parametrize("H,W,mH,mW", [(5, 5, 9, 9), (5, 7, 9, 13), (6, 6, 5, 5), (8, 8, 15, 15)])
+def test_psamask_nhwc_vs_oracle(H, W, mH, mW, report):
+    """Pixel-major form used inside the engine == the reference op up to the layout permutation."""
+    import numpy as np
+    from oracle import psamask as orc
+    from semseg_amd import ops
+    N, HW, T = 2, H * W, mH * mW
+    rng = np.random.default_rng(H * 100 + mW)
+    x = rng.standard_normal((N, T, H, W)).astype(np.float32)       # reference layout
+    gy = rng.standard_normal((N, HW, H, W)).astype(np.float32)
+    ldm, lda = ops.roundup(T, 128), ops.roundup(HW, 128)
+    for t in (0, 1):
+        ref_f = orc.psa_mask_forward(x, t, mH, mW)                  # [N, p, h, w]
+        ref_b = orc.psa_mask_backward(gy, t, mH, mW)                # [N, taps, h, w]
+        m = torch.zeros(N * HW, ldm, device=DEV)
+        m[:, :T] = torch.from_numpy(x).permute(0, 2, 3, 1).reshape(N * HW, T).to(DEV)
+        a = torch.full((N * HW, lda), 5.0, device=DEV)
+        ops.psamask_nhwc_forward(t, m, ldm, a, lda, N, H, W, mH, mW)
+        got = a[:, :HW].view(N, HW, HW).permute(0, 2, 1).reshape(N, HW, H, W)   # [n, p, q]
+        assert np.array_equal(got.cpu().numpy(), ref_f), "fwd type %d" % t
+        da = torch.zeros(N * HW, lda, device=DEV)
+        da[:, :HW] = torch.from_numpy(gy).reshape(N, HW, HW).permute(0, 2, 1).reshape(N * HW, HW).to(DEV)
+        dm = torch.full((N * HW, ldm), 3.0, device=DEV)
+        ops.psamask_nhwc_backward(t, da, lda, dm, ldm, N, H, W, mH, mW)
+        gotb = dm[:, :T].view(N, H, W, T).permute(0, 3, 1, 2)
+        assert np.array_equal(gotb.cpu().numpy(), ref_b), "bwd type %d" % t
+    report("psamask nhwc H=%d W=%d mask %dx%d bit-exact" % (H, W, mH, mW))
+
+
+def test_softmax_rows_and_transpose(report):
+    from semseg_amd import ops
+    rows, P, ld = 37, 900, 1024
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(rows, P, generator=g) * 4).double().requires_grad_(True)
+    y = torch.softmax(x, 1) * 0.25
+    dy = torch.randn(rows, P, generator=g).double()
+    y.backward(dy)
+    xb = torch.zeros(rows, ld, device=DEV); xb[:, :P] = x.detach().float().to(DEV)
+    yb = torch.zeros(rows, ld, device=DEV)
+    ops.softmax_rows_fwd(xb, ld, yb, ld, rows, P, 0.25, True)
+    dyb = torch.zeros(rows, ld, device=DEV); dyb[:, :P] = dy.float().to(DEV)
+    ops.softmax_rows_bwd(yb, ld, dyb, ld, dyb, ld, rows, P, 0.25, True)
+    e1, e2 = relerr(yb[:, :P], y), relerr(dyb[:, :P], x.grad)
+    # transpose
+    B, R, C = 3, 45, 70
+    t = torch.randn(B, R, C, generator=g)
+    out = torch.full((B, C, 64), 9.0, device=DEV)
+    ops.transpose_batched(t.to(DEV), C, R * C, out, 64, C * 64, B, R, C)
+    ok = torch.equal(out[:, :, :R].cpu(), t.transpose(1, 2)) and float(out[:, :, R:].abs().max()) == 0.0
+    report("softmax rows fwd %.2e bwd %.2e transpose %s" % (e1, e2, ok))
+    assert e1 < 1e-6 and e2 < 1e-5 and ok
+
+
+def test_gemm_entry_points(report):
+    """The raw-pointer GEMM forms used for the PSA point-affinity contraction (torch.bmm in
+    model/psanet.py:90-91) and its two gradients."""
+    from semseg_amd import ops
+    g = torch.Generator().manual_seed(4)
+    hw, C, P = 100, 512, 128
+    A = torch.zeros(hw + 128, P); A[:hw, :hw] = torch.randn(hw, hw, generator=g)
+    X = torch.zeros(hw + 128, C); X[:hw] = torch.randn(hw, C, generator=g)
+    Z = A[:hw, :hw].double() @ X[:hw].double()
+    Ad, Xd = A.to(DEV), X.to(DEV)
+    XT = torch.zeros(C + 128, P, device=DEV)
+    ops.transpose_batched(Xd, C, hw * C, XT, P, C * P, 1, hw, C)
+    Zd = torch.zeros(hw, C, device=DEV)
+    ops.gemm_rows(Ad.data_ptr(), P, XT.data_ptr(), Zd.data_ptr(), C, hw, P, C)
+    dZ = torch.randn(hw, C, generator=g)
+    dA = dZ.double() @ X[:hw].double().t()
+    dX = A[:hw, :hw].double().t() @ dZ.double()
+    dZd = dZ.to(DEV)
+    dAd = torch.zeros(hw + 128, P, device=DEV)
+    ops.gemm_rows(dZd.data_ptr(), C, Xd.data_ptr(), dAd.data_ptr(), P, hw, C, hw)
+    dXd = torch.zeros(hw, C, device=DEV)
+    scratch = torch.empty(8 * 1024 * 1024, device=DEV)
+    ops.gemm_kmajor(dZd.data_ptr(), C, Ad.data_ptr(), P, dXd.data_ptr(), scratch, hw, C, hw)
+    e = (relerr(Zd, Z), relerr(dAd[:hw, :hw], dA), relerr(dXd, dX))
+    report("psa contraction gemms: fwd %.2e dA %.2e dX %.2e" % e)
+    assert max(e) < 1e-5 and float(dAd[:hw, hw:].abs().max()) == 0.0
