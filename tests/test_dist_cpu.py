@@ -1,0 +1,109 @@
+"""CPU, gloo, world_size 2: the protocol of the N>1 path without kernels —
+ (1) SyncBN: all-reducing the per-rank [sum, sum of squares] fp64 vectors and finalising with the global
+     count reproduces full-batch BatchNorm statistics (what semseg_bn_finalize consumes);
+ (2) SyncBN backward: all-reduced [sum g, sum g*xhat] reproduce the full-batch input gradient;
+ (3) gradient buckets: contiguous, disjoint, cover every parameter, fire exactly once, heads first.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(11)
+        C, N, HW = 8, 4, 5
+        x = (torch.randn(N, C, HW, HW, generator=g) * 2 + 1).double()
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).double(), torch.randn(C, generator=g).double()
+        dout = torch.randn(N, C, HW, HW, generator=g).double()
+        per = N // world
+        xl, dl = x[rank * per:(rank + 1) * per], dout[rank * per:(rank + 1) * per]
+        # forward protocol
+        stats = torch.cat([xl.sum((0, 2, 3)), (xl * xl).sum((0, 2, 3))])
+        dist.all_reduce(stats)
+        cnt = per * HW * HW * world
+        mean = stats[:C] / cnt
+        var = stats[C:] / cnt - mean * mean
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        xf = x.clone().requires_grad_(True)
+        ref = F.batch_norm(xf, None, None, gamma, beta, True, 0.1, 1e-5)
+        yl = (xl - mean.view(1, C, 1, 1)) * (invstd * gamma).view(1, C, 1, 1) + beta.view(1, C, 1, 1)
+        ok_fwd = torch.allclose(yl, ref[rank * per:(rank + 1) * per].detach(), atol=1e-10)
+        # backward protocol: parameter gradients from LOCAL sums, input gradient from GLOBAL sums
+        ref.backward(dout)
+        xh = (xl - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
+        sums = torch.cat([dl.sum((0, 2, 3)), (dl * xh).sum((0, 2, 3))])
+        dist.all_reduce(sums)
+        dxl = (gamma * invstd).view(1, C, 1, 1) * (dl - (sums[:C] / cnt).view(1, C, 1, 1) -
+                                                  xh * (sums[C:] / cnt).view(1, C, 1, 1))
+        ok_bwd = torch.allclose(dxl, xf.grad[rank * per:(rank + 1) * per], atol=1e-10)
+        q.put((rank, bool(ok_fwd), bool(ok_bwd)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_protocol_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True, True), (1, True, True)], res
+
+
+def test_gradient_buckets_cover_parameters_once():
+    from model.pspnet import PSPNet
+    from semseg_amd.trainer import Trainer
+
+    class _E:
+        pass
+    m = PSPNet(layers=50, classes=5, pretrained=False)
+    tr = Trainer.__new__(Trainer)
+    tr.model = m
+    tr.params = list(m.parameters())
+    tr.offsets, off = {}, 0
+    for p in tr.params:
+        tr.offsets[p] = (off, p.numel())
+        off += ((p.numel() + 3) // 4) * 4
+    tr.bucket_elems = 4 * 1024 * 1024 // 4
+    e = _E()
+    tr._make_buckets(e)
+    spans = sorted((lo, hi) for lo, hi, _ in e._buckets)
+    assert spans[0][0] == 0 and spans[-1][1] == off
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))           # contiguous, disjoint
+    members = [p for _, _, ps in e._buckets for p in ps]
+    assert len(members) == len(tr.params) and len({id(p) for p in members}) == len(tr.params)
+    for lo, hi, ps in e._buckets:
+        for p in ps:
+            o, n = tr.offsets[p]
+            assert lo <= o and o + n <= hi
+    # the first bucket holds the heads (their gradients are produced first in backward)
+    assert any(p is m.aux[4].bias for p in e._buckets[0][2])
+    assert len(e._buckets) > 4
+
+
+def test_poly_lr_matches_reference_formula():
+    from semseg_amd.trainer import poly_learning_rate
+    # util/util.py:34-37: base_lr * (1 - curr_iter / max_iter) ** power
+    assert poly_learning_rate(0.01, 0, 100) == pytest.approx(0.01)
+    assert poly_learning_rate(0.01, 50, 100, 0.9) == pytest.approx(0.01 * 0.5 ** 0.9)

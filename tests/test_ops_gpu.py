@@ -453,3 +453,30 @@ def test_gemm_entry_points(report):
     e = (relerr(Zd, Z), relerr(dAd[:hw, :hw], dA), relerr(dXd, dX))
     report("psa contraction gemms: fwd %.2e dA %.2e dX %.2e" % e)
     assert max(e) < 1e-5 and float(dAd[:hw, hw:].abs().max()) == 0.0
+
+
+def test_lib_psa_functional_dropin(report):
+    """`lib.psa.functional.psa_mask` (the reference's Python op API) forward + autograd backward against
+    the golden vectors produced by the reference's compiled CPU op."""
+    import os
+    import numpy as np
+    import lib.psa.functional as PF
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "psamask_ref.npz"))
+    keys = sorted({k.rsplit("_", 1)[0] for k in fx.files})
+    for key in keys:
+        parts = key.split("_")
+        mH, mW = (int(v) for v in parts[2][1:].split("x"))
+        t = int(parts[3][1:])
+        x = torch.from_numpy(fx[key + "_x"]).to(DEV).requires_grad_(True)
+        out = PF.psa_mask(x, t, mH, mW)
+        out.backward(torch.from_numpy(fx[key + "_gy"]).to(DEV))
+        assert np.array_equal(out.detach().cpu().numpy(), fx[key + "_out"]), key
+        assert np.array_equal(x.grad.cpu().numpy(), fx[key + "_gin"]), key
+    # default mask size = 2*feature-1 and the argument checks of functions/psamask.py:9-15
+    x = torch.randn(1, 49, 4, 4, device=DEV)
+    assert PF.psa_mask(x).shape == (1, 16, 4, 4)
+    with pytest.raises(AssertionError):
+        PF.psa_mask(x, 0, 6, 6)
+    with pytest.raises(RuntimeError):
+        PF.psa_mask(torch.randn(1, 49, 4, 4))
+    report("lib.psa.functional.psa_mask == reference golden vectors (%d cases), checks ok" % len(keys))
