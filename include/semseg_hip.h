@@ -39,17 +39,19 @@ int semseg_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_dgrad, 
                              int R, int S, int Co_pad, int Ci_pad, hipStream_t stream);
 /* y[M][Co] = conv(x) (+bias) (+add); stats (optional, [2*Co] fp64, caller-zeroed) receives the
  * per-channel sum and sum of squares of y for the following BatchNorm.  tile_n in {64,128};
- * w_fwd must have Co_pad = roundup(Co, tile_n) rows.  Ci % 32 == 0. */
+ * w_fwd must have Co_pad = roundup(Co, tile_n) rows.  Ci % 32 == 0.  scratch (optional) enables
+ * split-K when the 128 x tile_n tile grid cannot fill the 256 CUs (small per-GPU batches). */
 int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
                     int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
                     int dil, const float* bias, const float* add, int ldadd, double* stats,
-                    int tile_n, hipStream_t stream);
+                    int stats_nslot, int tile_n, float* scratch, size_t scratch_floats,
+                    hipStream_t stream);
 /* dx[N*H*W][Ci] = conv_transpose(dy) (+add).  dy must be readable (zero padded) up to
  * roundup32(Co) channels; w_dgrad must have roundup(Ci, tile_n) rows. */
 int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
-                      int pad, int dil, const float* add, int ldadd, int tile_n,
-                      hipStream_t stream);
+                      int pad, int dil, const float* add, int ldadd, int tile_n, float* scratch,
+                      size_t scratch_floats, hipStream_t stream);
 /* dw_oihw[Co][Ci][R][S] (=|+=) sum over pixels; scratch holds the split-K partial slabs
  * (>= semseg_conv_wgrad_scratch_floats(...) floats; more slabs => more K parallelism).
  * dy must be readable (zero padded) up to roundup(Co, 64 or 128) channels.  Ci % 64 == 0. */
@@ -67,9 +69,13 @@ int semseg_stem_conv_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_
 
 /* ---- nn.BatchNorm2d / nn.SyncBatchNorm (+ReLU, +residual, +Dropout2d) — model/resnet.py:64-69,
  * 88-92,109-113,136; model/pspnet.py:16-17,66-68,74-76; tool/train.py:142.
- * stats / sums are [2*C] fp64 vectors (caller-zeroed): exactly what SyncBN all-reduces. */
-int semseg_channel_stats(const float* x, int ldx, double* stats, int M, int C, hipStream_t stream);
-int semseg_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+ * stats / sums are [nslot][2*C] fp64 vectors (caller-zeroed): producers scatter their atomics over the
+ * nslot replicas (same-address fp64 atomics serialise), consumers combine them; the combined slot 0
+ * ([2*C]) is exactly what SyncBN all-reduces. */
+int semseg_channel_stats(const float* x, int ldx, double* stats, int nslot, int M, int C,
+                         hipStream_t stream);
+int semseg_bn_combine(double* stats, int nslot, int C, hipStream_t stream);
+int semseg_bn_finalize(const double* stats, int nslot, double count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, long long* num_batches_tracked,
                        float momentum, float eps, float* mean, float* invstd, float* scale,
                        float* shift, int C, hipStream_t stream);
@@ -84,14 +90,15 @@ int semseg_bn_apply(const float* y, int ldy, const float* scale, const float* sh
 /* g = dout (*dropmask) (*[out>0]); sums += {sum g, sum g*xhat}; g optionally written. */
 int semseg_bn_bwd_reduce(const float* dout, int lddout, const float* out, int ldout,
                          const float* dropmask, int HW, const float* y, int ldy, const float* mean,
-                         const float* invstd, float* g, int ldg, double* sums, int M, int C,
-                         hipStream_t stream);
-/* dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count) */
+                         const float* invstd, float* g, int ldg, double* sums, int nslot, int M,
+                         int C, hipStream_t stream);
+/* dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count); sums = combined slot 0 */
 int semseg_bn_bwd_apply(const float* g, int ldg, const float* y, int ldy, const float* mean,
                         const float* invstd, const float* gamma, const double* sums, double count,
                         float* dy, int lddy, int M, int C, hipStream_t stream);
-int semseg_bn_param_grads(const double* sums, float* dgamma, float* dbeta, int C, int accumulate,
-                          hipStream_t stream);
+/* combines the nslot replicas of sums into slot 0 and writes dgamma = sum g*xhat, dbeta = sum g */
+int semseg_bn_param_grads(double* sums, int nslot, float* dgamma, float* dbeta, int C,
+                          int accumulate, hipStream_t stream);
 
 /* ---- spatial ops: MaxPool2d(3,2,1) model/resnet.py:115; AdaptiveAvgPool2d model/pspnet.py:14;
  * F.interpolate(bilinear, align_corners=True) model/pspnet.py:25,95,100; model/psanet.py:61,78,97. */

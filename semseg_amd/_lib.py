@@ -7,7 +7,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "semseg_hip.h")
-LIB_PATH = os.path.join(HERE, "csrc", "libsemseg_hip.so")
+LIB_PATH = os.environ.get("SEMSEG_HIP_LIB") or os.path.join(HERE, "csrc", "libsemseg_hip.so")  # override: kernel tuning only
 
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,

@@ -29,9 +29,11 @@ inline Tiling make_tiling(int CV) {
   return t;
 }
 
+// Same-address fp64 atomics serialise at ~70 ns each, so the per-channel accumulators are replicated
+// NSLOT times ([nslot][2C], slot = block % nslot) and combined by the consumer kernel.
 inline int rows_grid(int M, int rpb, int gx) {
-  int gy = (M + rpb - 1) / rpb;
-  int cap = 2048 / gx;
+  int gy = (M + rpb * 4 - 1) / (rpb * 4);
+  int cap = 768 / gx;
   if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
@@ -62,7 +64,8 @@ __device__ __forceinline__ void block_reduce_atomic(double (&v)[NV], int tpr, in
 
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int ldx,
                                                             double* __restrict__ stats, int M,
-                                                            int C, int tpr, int rpb) {
+                                                            int C, int tpr, int rpb, int nslot) {
+  stats += (size_t)((blockIdx.x + blockIdx.y) % nslot) * 2 * C;
   extern __shared__ double sred[];
   const int CV = C >> 2;
   const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
@@ -70,14 +73,25 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
   const bool active = c4 < CV;
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (active) {
-    for (int m = blockIdx.y * rpb + tr; m < M; m += gridDim.y * rpb) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + c4 * 4);
+    constexpr int U = 4;
+    const int step = gridDim.y * rpb;
+    for (int mb = blockIdx.y * rpb + tr; mb < M; mb += U * step) {
+      f32x4 a[U];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const double d = (double)a[k];
-        v[k] += d;
-        v[4 + k] += d * d;
+      for (int u = 0; u < U; ++u) {
+        const int m = mb + u * step;
+        a[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(m < M ? m : mb) * ldx + c4 * 4);
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (mb + u * step < M) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const double d = (double)a[u][k];
+            v[k] += d;
+            v[4 + k] += d * d;
+          }
+        }
     }
   }
   double* dst[8];
@@ -90,7 +104,15 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 }
 
 // sums -> mean / invstd / scale / shift; running-stat update (train)
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count,
+__global__ void bn_combine_kernel(double* stats, int nslot, int C2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C2) return;
+  double v = stats[c];
+  for (int s = 1; s < nslot; ++s) v += stats[(size_t)s * C2 + c];
+  stats[c] = v;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int nslot, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long long* nbt,
                                    float momentum, float eps, float* __restrict__ mean,
@@ -99,8 +121,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
-  const double mu = stats[c] / count;
-  double var = stats[C + c] / count - mu * mu;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < nslot; ++s) {
+    s1 += stats[(size_t)s * 2 * C + c];
+    s2 += stats[(size_t)s * 2 * C + C + c];
+  }
+  const double mu = s1 / count;
+  double var = s2 / count - mu * mu;
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float m = (float)mu;
@@ -173,7 +200,7 @@ struct BwdReduceArgs {
   const float* y; const float* mean; const float* invstd;
   float* g; double* sums;
   int lddout, ldout, ldy, ldg;
-  int M, C, HW, tpr, rpb;
+  int M, C, HW, tpr, rpb, nslot;
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdReduceArgs p) {
@@ -187,32 +214,45 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdReduceArgs 
     const int c = c4 * 4;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c);
     const f32x4 is = *reinterpret_cast<const f32x4*>(p.invstd + c);
-    for (int m = blockIdx.y * p.rpb + tr; m < p.M; m += gridDim.y * p.rpb) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(p.dout + (size_t)m * p.lddout + c);
-      if (p.dropmask) {
-        const int n = m / p.HW;
-        g *= *reinterpret_cast<const f32x4*>(p.dropmask + (size_t)n * p.C + c);
-      }
-      if (p.out) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(p.out + (size_t)m * p.ldout + c);
+    // U rows in flight per thread: all loads of a group are issued before any is consumed
+    constexpr int U = 4;
+    const int step = gridDim.y * p.rpb;
+    const f32x4 dmz = {1.f, 1.f, 1.f, 1.f};
+    for (int mb = blockIdx.y * p.rpb + tr; mb < p.M; mb += U * step) {
+      f32x4 gg[U], oo[U], yy[U], dd[U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+      for (int u = 0; u < U; ++u) {
+        const int m = mb + u * step;
+        const int mc = m < p.M ? m : mb;
+        gg[u] = *reinterpret_cast<const f32x4*>(p.dout + (size_t)mc * p.lddout + c);
+        yy[u] = *reinterpret_cast<const f32x4*>(p.y + (size_t)mc * p.ldy + c);
+        oo[u] = p.out ? *reinterpret_cast<const f32x4*>(p.out + (size_t)mc * p.ldout + c) : dmz;
+        dd[u] = p.dropmask ? *reinterpret_cast<const f32x4*>(p.dropmask + (size_t)(mc / p.HW) * p.C + c) : dmz;
       }
-      if (p.g) *reinterpret_cast<f32x4*>(p.g + (size_t)m * p.ldg + c) = g;
-      const f32x4 yy = *reinterpret_cast<const f32x4*>(p.y + (size_t)m * p.ldy + c);
-      const f32x4 xh = (yy - mu) * is;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[k] += (double)g[k];
-        v[4 + k] += (double)g[k] * (double)xh[k];
+      for (int u = 0; u < U; ++u) {
+        const int m = mb + u * step;
+        if (m < p.M) {
+          f32x4 g = gg[u] * dd[u];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g[k] = oo[u][k] > 0.f ? g[k] : 0.f;
+          if (p.g) *reinterpret_cast<f32x4*>(p.g + (size_t)m * p.ldg + c) = g;
+          const f32x4 xh = (yy[u] - mu) * is;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[k] += (double)g[k];
+            v[4 + k] += (double)g[k] * (double)xh[k];
+          }
+        }
       }
     }
   }
   double* dst[8];
+  double* sl = p.sums + (size_t)((blockIdx.x + blockIdx.y) % p.nslot) * 2 * p.C;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    dst[k] = p.sums + c4 * 4 + k;
-    dst[4 + k] = p.sums + p.C + c4 * 4 + k;
+    dst[k] = sl + c4 * 4 + k;
+    dst[4 + k] = sl + p.C + c4 * 4 + k;
   }
   block_reduce_atomic<8>(v, p.tpr, p.rpb, tr, tc, sred, dst, active);
 }
@@ -250,11 +290,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
   }
 }
 
-__global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* dgamma, float* dbeta,
+// combines the nslot partial vectors into slot 0 (what bn_bwd_apply / the SyncBN all-reduce read)
+// and emits the parameter gradients from the LOCAL sums
+__global__ void bn_param_grads_kernel(double* sums, int nslot, float* dgamma, float* dbeta,
                                       int C, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float dg = (float)sums[C + c], db = (float)sums[c];
+  double s1 = sums[c], s2 = sums[C + c];
+  for (int s = 1; s < nslot; ++s) {
+    s1 += sums[(size_t)s * 2 * C + c];
+    s2 += sums[(size_t)s * 2 * C + C + c];
+  }
+  sums[c] = s1;
+  sums[C + c] = s2;
+  const float dg = (float)s2, db = (float)s1;
   dgamma[c] = accumulate ? dgamma[c] + dg : dg;
   dbeta[c] = accumulate ? dbeta[c] + db : db;
 }
@@ -270,20 +319,29 @@ inline int flat_grid(size_t total) {
 
 extern "C" {
 
-int semseg_channel_stats(const float* x, int ldx, double* stats, int M, int C, hipStream_t stream) {
-  if (!x || !stats || (C & 3) || (ldx & 3) || M <= 0) return SEMSEG_EINVAL;
+int semseg_channel_stats(const float* x, int ldx, double* stats, int nslot, int M, int C,
+                         hipStream_t stream) {
+  if (!x || !stats || (C & 3) || (ldx & 3) || M <= 0 || nslot < 1) return SEMSEG_EINVAL;
   const Tiling t = make_tiling(C >> 2);
   dim3 grid(t.gx, rows_grid(M, t.rpb, t.gx));
-  channel_stats_kernel<<<grid, 256, 256 * 8 * sizeof(double), stream>>>(x, ldx, stats, M, C, t.tpr, t.rpb);
+  channel_stats_kernel<<<grid, 256, 256 * 8 * sizeof(double), stream>>>(x, ldx, stats, M, C, t.tpr, t.rpb,
+                                                                       nslot);
   return semseg_launch_status();
 }
 
-int semseg_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+int semseg_bn_combine(double* stats, int nslot, int C, hipStream_t stream) {
+  if (!stats || nslot < 1) return SEMSEG_EINVAL;
+  bn_combine_kernel<<<(2 * C + 255) / 256, 256, 0, stream>>>(stats, nslot, 2 * C);
+  return semseg_launch_status();
+}
+
+int semseg_bn_finalize(const double* stats, int nslot, double count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, long long* num_batches_tracked,
                        float momentum, float eps, float* mean, float* invstd, float* scale,
                        float* shift, int C, hipStream_t stream) {
-  if (!stats || !gamma || !beta || !mean || !invstd || !scale || !shift || count <= 0) return SEMSEG_EINVAL;
-  bn_finalize_kernel<<<(C + 255) / 256, 256, 0, stream>>>(stats, count, gamma, beta, running_mean,
+  if (!stats || !gamma || !beta || !mean || !invstd || !scale || !shift || count <= 0 || nslot < 1)
+    return SEMSEG_EINVAL;
+  bn_finalize_kernel<<<(C + 255) / 256, 256, 0, stream>>>(stats, nslot, count, gamma, beta, running_mean,
                                                         running_var, num_batches_tracked, momentum,
                                                         eps, mean, invstd, scale, shift, C);
   return semseg_launch_status();
@@ -313,12 +371,13 @@ int semseg_bn_apply(const float* y, int ldy, const float* scale, const float* sh
 
 int semseg_bn_bwd_reduce(const float* dout, int lddout, const float* out, int ldout,
                          const float* dropmask, int HW, const float* y, int ldy, const float* mean,
-                         const float* invstd, float* g, int ldg, double* sums, int M, int C,
-                         hipStream_t stream) {
-  if (!dout || !y || !mean || !invstd || !sums || (C & 3) || (lddout & 3) || (ldy & 3)) return SEMSEG_EINVAL;
+                         const float* invstd, float* g, int ldg, double* sums, int nslot, int M,
+                         int C, hipStream_t stream) {
+  if (!dout || !y || !mean || !invstd || !sums || (C & 3) || (lddout & 3) || (ldy & 3) || nslot < 1)
+    return SEMSEG_EINVAL;
   const Tiling t = make_tiling(C >> 2);
   BwdReduceArgs a{dout, out, dropmask, y, mean, invstd, g, sums,
-                  lddout, ldout, ldy, ldg, M, C, HW, t.tpr, t.rpb};
+                  lddout, ldout, ldy, ldg, M, C, HW, t.tpr, t.rpb, nslot};
   dim3 grid(t.gx, rows_grid(M, t.rpb, t.gx));
   bn_bwd_reduce_kernel<<<grid, 256, 256 * 8 * sizeof(double), stream>>>(a);
   return semseg_launch_status();
@@ -333,10 +392,10 @@ int semseg_bn_bwd_apply(const float* g, int ldg, const float* y, int ldy, const 
   return semseg_launch_status();
 }
 
-int semseg_bn_param_grads(const double* sums, float* dgamma, float* dbeta, int C, int accumulate,
-                          hipStream_t stream) {
-  if (!sums || !dgamma || !dbeta) return SEMSEG_EINVAL;
-  bn_param_grads_kernel<<<(C + 255) / 256, 256, 0, stream>>>(sums, dgamma, dbeta, C, accumulate);
+int semseg_bn_param_grads(double* sums, int nslot, float* dgamma, float* dbeta, int C,
+                          int accumulate, hipStream_t stream) {
+  if (!sums || !dgamma || !dbeta || nslot < 1) return SEMSEG_EINVAL;
+  bn_param_grads_kernel<<<(C + 255) / 256, 256, 0, stream>>>(sums, nslot, dgamma, dbeta, C, accumulate);
   return semseg_launch_status();
 }
 

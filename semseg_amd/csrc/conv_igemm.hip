@@ -19,6 +19,20 @@ namespace {
 constexpr int BK = 32;   // K-step (floats)
 constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 conflict-free
 
+// tuning knobs (scripts/tune_conv.py builds variants with -D...)
+#ifndef CONV_OCC
+#define CONV_OCC 1
+#endif
+#ifndef CONV_DBUF
+#define CONV_DBUF 0
+#endif
+#ifndef CONV_PRIO
+#define CONV_PRIO 0
+#endif
+#ifndef CONV_ABL   // ablation (timing only, results wrong): 1 no global prefetch, 2 +no LDS store/barrier, 3 +no LDS read
+#define CONV_ABL 0
+#endif
+
 struct ConvArgs {
   const float* x;   // A source: activations (fwd) or output-gradient (dgrad), NHWC
   const float* w;   // packed B^T panel [Nout_pad][KT*32]
@@ -34,13 +48,18 @@ struct ConvArgs {
   int R, S, stride, pad, dil;
   int M;              // N*Hout*Wout
   int tiles_n;
+  int stats_nslot;    // stats is [nslot][2*Nout]; tile_m % nslot picks the replica
+  int ksplit, kt_per; // split-K: workgroup (tile, ks) covers K-steps [ks*kt_per, (ks+1)*kt_per)
+  float* part;        // split-K partial slabs [ksplit][M][ldpart]
+  int ldpart;
 };
 
 template <int BM, int BN, bool TR>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int MREP = BM / 64, NREP = BN / 64;
   constexpr int A_PER = BM / 32, B_PER = BN / 32;
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+  constexpr int STAGE = (BM + BN) * LDK;
+  __shared__ __attribute__((aligned(16))) float smem[(CONV_DBUF ? 2 : 1) * STAGE];
   float* As = smem;
   float* Bs = smem + BM * LDK;
 
@@ -50,75 +69,102 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = logical % p.tiles_n;
-  const int tile_m = logical / p.tiles_n;
+  const int ks = logical % p.ksplit;
+  const int tile = logical / p.ksplit;
+  const int tile_n = tile % p.tiles_n;
+  const int tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int RS = p.R * p.S;
   const int nchunk = p.Kc / BK;
-  const int KT = RS * nchunk;
-  const size_t wK = (size_t)KT * BK;  // packed panel row length
+  const int KT_all = RS * nchunk;
+  const size_t wK = (size_t)KT_all * BK;  // packed panel row length
+  const int kt0 = ks * p.kt_per;
+  const int KT = min(KT_all, kt0 + p.kt_per);  // this workgroup walks K-steps [kt0, KT)
 
   // ---- per-thread staging assignment ----
+  // The gather address of (row, tap) is separable: off = rowbase[row] + tapoff(tap) + channel, and
+  // its validity is one bit of a per-row tap mask, both computed once here; the K loop then walks
+  // (chunk, r, s) with scalar counters only (no divisions, no divergent branches around the loads).
   const int kq = tid & 7;     // which float4 of the 32-float K-step
   const int lrow = tid >> 3;  // 0..31
-  int a_n[A_PER], a_oh[A_PER], a_ow[A_PER];
-  bool a_ok[A_PER];
+  int a_base[A_PER];
+  unsigned a_mask[A_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int m = m0 + lrow + 32 * i;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
+    const bool rok = m < p.M;
+    const int mm = rok ? m : 0;
     const int hw = p.Hout * p.Wout;
-    a_n[i] = mm / hw;
-    const int rem = mm - a_n[i] * hw;
-    a_oh[i] = rem / p.Wout;
-    a_ow[i] = rem - a_oh[i] * p.Wout;
+    const int n = mm / hw;
+    const int rem = mm - n * hw;
+    const int oh = rem / p.Wout;
+    const int ow = rem - oh * p.Wout;
+    unsigned mask = 0;
+    int bh, bw;  // tap-independent part of the source coordinate
+    if (!TR) {
+      bh = oh * p.stride - p.pad;
+      bw = ow * p.stride - p.pad;
+    } else {
+      bh = (oh + p.pad) / p.stride;
+      bw = (ow + p.pad) / p.stride;
+    }
+    for (int r = 0; r < p.R; ++r)
+      for (int s = 0; s < p.S; ++s) {
+        bool ok = rok;
+        int ih, iw;
+        if (!TR) {
+          ih = bh + r * p.dil;
+          iw = bw + s * p.dil;
+        } else {
+          const int rd = r * p.dil, sd = s * p.dil;
+          ih = bh - rd / p.stride;
+          iw = bw - sd / p.stride;
+          ok = ok && ((oh + p.pad) % p.stride == rd % p.stride) && ((ow + p.pad) % p.stride == sd % p.stride);
+        }
+        ok = ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
+        if (ok) mask |= 1u << (r * p.S + s);
+      }
+    a_mask[i] = mask;
+    a_base[i] = ((n * p.Hin + bh) * p.Win + bw) * p.ldx + kq * 4;
   }
   const float* bptr[B_PER];
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) bptr[i] = p.w + (size_t)(n0 + lrow + 32 * i) * wK + kq * 4;
 
   f32x4 ra[A_PER], rb[B_PER];
+  // scalar K-walk state of the NEXT tile to prefetch
+  int pf_tap = kt0 % RS, pf_coff = (kt0 / RS) * BK;
+  int pf_r = pf_tap / p.S, pf_s = pf_tap - (pf_tap / p.S) * p.S;
 
   auto prefetch = [&](int kt) {
-    const int chunk = kt / RS;
-    const int tap = kt - chunk * RS;
-    const int r = tap / p.S;
-    const int s = tap - r * p.S;
-    const int coff = chunk * BK + kq * 4;
+    int toff;
+    if (!TR)
+      toff = (pf_r * p.dil * p.Win + pf_s * p.dil) * p.ldx;
+    else
+      toff = -(((pf_r * p.dil) / p.stride) * p.Win + (pf_s * p.dil) / p.stride) * p.ldx;
+    toff += pf_coff;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-      int ih, iw;
-      bool ok = a_ok[i];
-      if (!TR) {
-        ih = a_oh[i] * p.stride + r * p.dil - p.pad;
-        iw = a_ow[i] * p.stride + s * p.dil - p.pad;
-        ok = ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
-      } else {
-        const int th = a_oh[i] + p.pad - r * p.dil;
-        const int tw = a_ow[i] + p.pad - s * p.dil;
-        ok = ok && th >= 0 && tw >= 0;
-        if (p.stride == 1) {
-          ih = th;
-          iw = tw;
-        } else {
-          ih = th / p.stride;
-          iw = tw / p.stride;
-          ok = ok && (ih * p.stride == th) && (iw * p.stride == tw);
-        }
-        ok = ok && ih < p.Hin && iw < p.Win;
-      }
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const size_t off = ((size_t)(a_n[i] * p.Hin + ih) * p.Win + iw) * p.ldx + coff;
-        v = *reinterpret_cast<const f32x4*>(p.x + off);
-      }
-      ra[i] = v;
+      const bool ok = (a_mask[i] >> pf_tap) & 1u;
+      const int off = ok ? a_base[i] + toff : 0;  // row 0 of the tensor is always readable
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ra[i] = ok ? v : z;
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
       rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + (size_t)kt * BK);
+    // advance (tap fastest, then channel chunk)
+    ++pf_tap;
+    if (++pf_s == p.S) {
+      pf_s = 0;
+      if (++pf_r == p.R) {
+        pf_r = 0;
+        pf_tap = 0;
+        pf_coff += BK;
+      }
+    }
   };
 
   f32x16 acc[MREP][NREP];
@@ -129,27 +175,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  prefetch(0);
-  for (int kt = 0; kt < KT; ++kt) {
+  auto stage_store = [&](float* A_, float* B_) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i)
-      *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDK + kq * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&A_[(lrow + 32 * i) * LDK + kq * 4]) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
-      *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * LDK + kq * 4]) = rb[i];
-    __syncthreads();
-    if (kt + 1 < KT) prefetch(kt + 1);
+      *reinterpret_cast<f32x4*>(&B_[(lrow + 32 * i) * LDK + kq * 4]) = rb[i];
+  };
+  auto compute = [&](const float* A_, const float* B_) {
+#if CONV_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int k8 = 0; k8 < 4; ++k8) {
       f32x4 a[MREP], b[NREP];
+#if CONV_ABL == 3
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) { a[i] = ra[i]; asm volatile("" : "+v"(a[i])); }
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) { b[j] = rb[j]; asm volatile("" : "+v"(b[j])); }
+#else
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
         a[i] = *reinterpret_cast<const f32x4*>(
-            &As[(wm * (BM / 2) + i * 32 + l31) * LDK + k8 * 8 + lhi * 4]);
+            &A_[(wm * (BM / 2) + i * 32 + l31) * LDK + k8 * 8 + lhi * 4]);
 #pragma unroll
       for (int j = 0; j < NREP; ++j)
         b[j] = *reinterpret_cast<const f32x4*>(
-            &Bs[(wn * (BN / 2) + j * 32 + l31) * LDK + k8 * 8 + lhi * 4]);
+            &B_[(wn * (BN / 2) + j * 32 + l31) * LDK + k8 * 8 + lhi * 4]);
+#endif
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -158,7 +213,61 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           for (int j = 0; j < NREP; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
     }
+#if CONV_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+
+  prefetch(kt0);
+#if CONV_ABL
+  stage_store(As, Bs);
+  __syncthreads();
+  for (int kt = kt0; kt < KT; ++kt) {
+#if CONV_ABL == 1
+    stage_store(As, Bs);
     __syncthreads();
+#endif
+    compute(As, Bs);
+#if CONV_ABL == 1
+    __syncthreads();
+#endif
+  }
+#elif CONV_DBUF
+  stage_store(smem + (kt0 & 1) * STAGE, smem + (kt0 & 1) * STAGE + BM * LDK);
+  __syncthreads();
+  for (int kt = kt0; kt < KT; ++kt) {
+    float* cA = smem + (kt & 1) * STAGE;
+    float* nA = smem + ((kt + 1) & 1) * STAGE;
+    if (kt + 1 < KT) prefetch(kt + 1);
+    compute(cA, cA + BM * LDK);
+    if (kt + 1 < KT) stage_store(nA, nA + BM * LDK);
+    __syncthreads();
+  }
+#else
+  for (int kt = kt0; kt < KT; ++kt) {
+    stage_store(As, Bs);
+    __syncthreads();
+    if (kt + 1 < KT) prefetch(kt + 1);
+    compute(As, Bs);
+    __syncthreads();
+  }
+#endif
+
+  if (p.ksplit > 1) {
+    // raw partial tile; bias / add / statistics happen in splitk_epilogue_kernel
+    float* out = p.part + (size_t)ks * p.M * p.ldpart;
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          if (m < p.M) out[(size_t)m * p.ldpart + col] = acc[i][j][e];
+        }
+    }
+    return;
   }
 
   // ---- epilogue: store, optional bias / residual add, optional fp64 channel statistics ----
@@ -202,9 +311,73 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       if (col < p.Nout) {
         const double s1 = red[(0 * BN + tid) * 2 + 0] + red[(1 * BN + tid) * 2 + 0];
         const double s2 = red[(0 * BN + tid) * 2 + 1] + red[(1 * BN + tid) * 2 + 1];
-        atomic_add_f64(&p.stats[col], s1);
-        atomic_add_f64(&p.stats[p.Nout + col], s2);
+        double* st = p.stats + (size_t)(tile_m % p.stats_nslot) * 2 * p.Nout;
+        atomic_add_f64(&st[col], s1);
+        atomic_add_f64(&st[p.Nout + col], s2);
       }
+    }
+  }
+}
+
+// Split-K epilogue: y = sum_ks part[ks] (+bias) (+add); optional fp64 channel statistics.
+// Thread = one float4 of channels, rows strided over the grid (same tiling as the BN reductions).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part,
+                                                              int ksplit, int ldpart, float* y,
+                                                              int ldy, const float* bias,
+                                                              const float* add, int ldadd,
+                                                              double* stats, int nslot, int M,
+                                                              int Nout, int tpr, int rpb) {
+  __shared__ double sred[256 * 8];
+  const int CV = (Nout + 3) >> 2;
+  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+  const int c4 = blockIdx.x * tpr + tc;
+  const bool active = c4 < CV;
+  const int c = c4 * 4;
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (active) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bv[k] = (c + k < Nout) ? bias[c + k] : 0.f;
+    }
+    const size_t slab = (size_t)M * ldpart;
+    for (int m = blockIdx.y * rpb + tr; m < M; m += gridDim.y * rpb) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(part + (size_t)m * ldpart + c);
+      for (int k = 1; k < ksplit; ++k)
+        a += *reinterpret_cast<const f32x4*>(part + k * slab + (size_t)m * ldpart + c);
+      a += bv;
+      if (add) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (c + k < Nout) a[k] += add[(size_t)m * ldadd + c + k];
+      }
+      *reinterpret_cast<f32x4*>(y + (size_t)m * ldy + c) = a;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double d = (double)a[k];
+        v[k] += d;
+        v[4 + k] += d * d;
+      }
+    }
+  }
+  if (stats) {
+    if (rpb > 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sred[(tr * tpr + tc) * 8 + k] = v[k];
+      __syncthreads();
+      if (tr == 0)
+        for (int r = 1; r < rpb; ++r)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += sred[(r * tpr + tc) * 8 + k];
+    }
+    if (tr == 0 && active) {
+      double* st = stats + (size_t)((blockIdx.x + blockIdx.y) % nslot) * 2 * Nout;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c + k < Nout) {
+          atomic_add_f64(&st[c + k], v[k]);
+          atomic_add_f64(&st[Nout + c + k], v[4 + k]);
+        }
     }
   }
 }
@@ -214,6 +387,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 // One workgroup per (co tile, ci tile, tap, K split); partial sums go to a [ksplit] slab that
 // wgrad_reduce_unpack sums deterministically while converting to the OIHW layout of .grad.
 // ------------------------------------------------------------------------------------------
+// exact n / d for 0 <= n < 2^31 by one 64-bit multiply: q = (n * mul) >> sh
+struct FastDiv {
+  unsigned mul, sh;
+};
+inline FastDiv make_fastdiv(int d) {
+  int l = 0;
+  while ((1LL << l) < d) ++l;
+  FastDiv f;
+  f.sh = 31 + l;
+  f.mul = (unsigned)(((1ULL << f.sh) + (unsigned long long)d - 1) / (unsigned long long)d);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) {
+  return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh);
+}
+
 struct WgradArgs {
   const float* x;
   const float* dy;
@@ -225,6 +414,7 @@ struct WgradArgs {
   int M;      // N*Ho*Wo
   int ksplit, kper;  // kper: pixels per split (multiple of 32)
   int tiles_co, tiles_ci;
+  FastDiv div_hw, div_wo;
 };
 
 template <int TM, int TN>
@@ -258,30 +448,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const int hw = p.Ho * p.Wo;
 
   f32x4 ry[Y_PER], rx[X_PER];
+  const int tapoff = ((r * p.dil - p.pad) * p.Win + (s * p.dil - p.pad)) * p.ldx + ci0 + xc * 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto prefetch = [&](int kb) {
 #pragma unroll
     for (int i = 0; i < Y_PER; ++i) {
       const int m = kb + yr + i * YROWS;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < kend) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + co0 + yc * 4);
-      ry[i] = v;
+      const bool ok = m < kend;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)(ok ? m : kbeg) * p.lddy + co0 + yc * 4);
+      ry[i] = ok ? v : zero4;
     }
 #pragma unroll
     for (int i = 0; i < X_PER; ++i) {
       const int m = kb + xr + i * XROWS;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < kend) {
-        const int n = m / hw;
-        const int rem = m - n * hw;
-        const int oh = rem / p.Wo;
-        const int ow = rem - oh * p.Wo;
-        const int ih = oh * p.stride + r * p.dil - p.pad;
-        const int iw = ow * p.stride + s * p.dil - p.pad;
-        if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
-          v = *reinterpret_cast<const f32x4*>(
-              p.x + ((size_t)(n * p.Hin + ih) * p.Win + iw) * p.ldx + ci0 + xc * 4);
-      }
-      rx[i] = v;
+      const int mm = m < kend ? m : kbeg;
+      const int n = fdiv(mm, p.div_hw);
+      const int rem = mm - n * hw;
+      const int oh = fdiv(rem, p.div_wo);
+      const int ow = rem - oh * p.Wo;
+      const int ih = oh * p.stride + r * p.dil - p.pad;
+      const int iw = ow * p.stride + s * p.dil - p.pad;
+      const bool ok = m < kend && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
+      const int off = ok ? ((n * p.Hin + oh * p.stride) * p.Win + ow * p.stride) * p.ldx + tapoff
+                         : ci0 + xc * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);
+      rx[i] = ok ? v : zero4;
     }
   };
 
@@ -421,23 +612,54 @@ int semseg_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_dgrad, 
   return semseg_launch_status();
 }
 
-static int conv_launch(bool transposed, const ConvArgs& a, int BN, hipStream_t stream) {
+static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratch,
+                       size_t scratch_floats, hipStream_t stream) {
   const int tiles_m = (a.M + 127) / 128;
   ConvArgs p = a;
+  p.tiles_n = (a.Nout + BN - 1) / BN;
+  const int tiles = tiles_m * p.tiles_n;
+  const int KT = a.R * a.S * (a.Kc / BK);
+  // Split K when the tile grid cannot fill 256 CUs (small per-GPU batch): each (tile, ks) workgroup
+  // writes a raw partial slab, splitk_epilogue_kernel reduces + applies the epilogue.
+  int ksplit = 1;
+  p.ldpart = p.tiles_n * BN;
+  // (the epilogue kernel stores 16-byte lanes: y rows must be 16-byte aligned and padded to 4 channels)
+  if (scratch && tiles < 384 && (a.ldy & 3) == 0 && a.ldy >= ((a.Nout + 3) & ~3)) {
+    ksplit = (640 + tiles - 1) / tiles;
+    if (ksplit > KT / 4) ksplit = KT / 4;
+    if (ksplit > 16) ksplit = 16;
+    const size_t slab = (size_t)a.M * p.ldpart;
+    while (ksplit > 1 && slab * ksplit > scratch_floats) --ksplit;
+    if (ksplit < 1) ksplit = 1;
+  }
+  p.kt_per = (KT + ksplit - 1) / ksplit;
+  ksplit = (KT + p.kt_per - 1) / p.kt_per;
+  p.ksplit = ksplit;
+  p.part = scratch;
+  const int grid = tiles * ksplit;
   if (BN == 128) {
-    p.tiles_n = (a.Nout + 127) / 128;
-    const int grid = tiles_m * p.tiles_n;
     if (transposed)
       conv_igemm_kernel<128, 128, true><<<grid, 256, 0, stream>>>(p);
     else
       conv_igemm_kernel<128, 128, false><<<grid, 256, 0, stream>>>(p);
   } else {
-    p.tiles_n = (a.Nout + 63) / 64;
-    const int grid = tiles_m * p.tiles_n;
     if (transposed)
       conv_igemm_kernel<128, 64, true><<<grid, 256, 0, stream>>>(p);
     else
       conv_igemm_kernel<128, 64, false><<<grid, 256, 0, stream>>>(p);
+  }
+  if (ksplit > 1) {
+    const int CV = (a.Nout + 3) / 4;
+    int tpr = 1;
+    while (tpr * 2 <= CV && tpr * 2 <= 256) tpr *= 2;
+    const int rpb = 256 / tpr, gx = (CV + tpr - 1) / tpr;
+    int gy = (a.M + rpb - 1) / rpb;
+    int cap = 1024 / gx;
+    if (cap < 1) cap = 1;
+    if (gy > cap) gy = cap;
+    splitk_epilogue_kernel<<<dim3(gx, gy), 256, 0, stream>>>(scratch, ksplit, p.ldpart, a.y, a.ldy, a.bias,
+                                                            a.add, a.ldadd, a.stats, a.stats_nslot, a.M,
+                                                            a.Nout, tpr, rpb);
   }
   return semseg_launch_status();
 }
@@ -445,7 +667,8 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, hipStream_t s
 int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
                     int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
                     int dil, const float* bias, const float* add, int ldadd, double* stats,
-                    int tile_n, hipStream_t stream) {
+                    int stats_nslot, int tile_n, float* scratch, size_t scratch_floats,
+                    hipStream_t stream) {
   if (!x || !w_fwd || !y || Ci % 32 != 0 || (ldx & 3) || (tile_n != 64 && tile_n != 128))
     return SEMSEG_EINVAL;
   ConvArgs a;
@@ -453,14 +676,14 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
   a.ldx = ldx; a.ldy = ldy; a.ldadd = ldadd;
   a.N = N; a.Hin = H; a.Win = W; a.Hout = Ho; a.Wout = Wo;
   a.Kc = Ci; a.Nout = Co; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
-  a.M = N * Ho * Wo; a.tiles_n = 0;
-  return conv_launch(false, a, tile_n, stream);
+  a.M = N * Ho * Wo; a.tiles_n = 0; a.stats_nslot = stats_nslot > 0 ? stats_nslot : 1;
+  return conv_launch(false, a, tile_n, scratch, scratch_floats, stream);
 }
 
 int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
-                      int pad, int dil, const float* add, int ldadd, int tile_n,
-                      hipStream_t stream) {
+                      int pad, int dil, const float* add, int ldadd, int tile_n, float* scratch,
+                      size_t scratch_floats, hipStream_t stream) {
   if (!dy || !w_dgrad || !dx || (lddy & 3) || (tile_n != 64 && tile_n != 128)) return SEMSEG_EINVAL;
   const int Kc = (Co + 31) / 32 * 32;
   if (lddy < Kc) return SEMSEG_EINVAL;
@@ -469,8 +692,8 @@ int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx
   a.ldx = lddy; a.ldy = lddx; a.ldadd = ldadd;
   a.N = N; a.Hin = Ho; a.Win = Wo; a.Hout = H; a.Wout = W;
   a.Kc = Kc; a.Nout = Ci; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
-  a.M = N * H * W; a.tiles_n = 0;
-  return conv_launch(true, a, tile_n, stream);
+  a.M = N * H * W; a.tiles_n = 0; a.stats_nslot = 1;
+  return conv_launch(true, a, tile_n, scratch, scratch_floats, stream);
 }
 
 int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
@@ -491,6 +714,8 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
   a.Co_pad = a.tiles_co * TM;
   if (lddy < a.Co_pad) return SEMSEG_EINVAL;  // dy rows must be readable (zero padded) up to Co_pad
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil; a.M = M;
+  a.div_hw = make_fastdiv(Ho * Wo);
+  a.div_wo = make_fastdiv(Wo);
   const int tiles = a.tiles_co * a.tiles_ci * RS;
   const int ksteps = (M + 31) / 32;
   int ksplit = (1536 + tiles - 1) / tiles;

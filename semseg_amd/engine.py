@@ -97,8 +97,8 @@ class BNL:
         self.eps = float(mod.eps)
         self.momentum = 0.1 if mod.momentum is None else float(mod.momentum)
         C = self.C
-        self.stats = eng.alloc_f64(2 * C)
-        self.sums = eng.alloc_f64(2 * C)
+        self.stats = eng.alloc_f64(2 * C * ops.NSLOT)   # [NSLOT][2C]; slot 0 holds the combined vector
+        self.sums = eng.alloc_f64(2 * C * ops.NSLOT)
         v = torch.empty(4 * C, dtype=F32, device=eng.device)
         self.mean, self.invstd, self.scale, self.shift = v[:C], v[C:2 * C], v[2 * C:3 * C], v[3 * C:]
         self.ggrad = None
@@ -146,7 +146,7 @@ class Engine:
             total = 0
             for m in self.model.modules():
                 if isinstance(m, nn.modules.batchnorm._BatchNorm):
-                    total += 4 * m.num_features
+                    total += 4 * m.num_features * ops.NSLOT
             total += 4096
             self._f64_arena = torch.zeros(total, dtype=F64, device=self.device)
             self._f64_cap = total
@@ -226,7 +226,8 @@ class Engine:
             out = self.act(x.N, Ho, Wo, cl.Co, ld=ld, tag="conv")
         ev = self._t0("conv_igemm_kernel<128,%d,false>" % cl.pk.tile_fwd, 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
         ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                     bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats)
+                     bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats,
+                     nslot=ops.NSLOT, scratch=self.scratch())
         self._t1(ev)
         if self.training:
             self.tape.append(lambda: self._conv_bwd(x, out, cl, m))
@@ -235,8 +236,7 @@ class Engine:
     def _conv_bwd(self, x, y, cl, m):
         dy = y.grad
         assert dy is not None
-        if self.wgrad_scratch is None:
-            self.wgrad_scratch = torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device)
+        self.scratch()
         flops = 2.0 * y.M * cl.Co * cl.Ci * cl.R * cl.S
         big = cl.Ci % 128 == 0 and cl.Co >= 128
         ev = self._t0("conv_wgrad_kernel<%d,%d>+reduce" % ((128, 128) if big else (64, 64)), flops)
@@ -256,10 +256,16 @@ class Engine:
             gx = self.grad_of(x)
             ev = self._t0("conv_igemm_kernel<128,%d,true>" % cl.pk.tile_dgrad, flops)
             ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                           add=gx if x.ginit else None, ldadd=x.ld)
+                           add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
             self._t1(ev)
             x.ginit = True
         self._ready(ready)
+
+    def scratch(self):
+        """256 MB arena for split-K partial slabs (conv fwd/dgrad at small batch, every wgrad)."""
+        if self.wgrad_scratch is None:
+            self.wgrad_scratch = torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device)
+        return self.wgrad_scratch
 
     def _t0(self, family, flops):
         if self.ktimer is None:
@@ -295,8 +301,14 @@ class Engine:
         """stats -> scale/shift (train: batch statistics, SyncBN all-reduce; eval: running stats)."""
         bl = self.bns[bm]
         if self.training and bm.training:
-            mult = self._sync(bl.stats)
-            cnt = count * mult
+            ns = ops.NSLOT
+            if (self.sync_bn or self.force_sync_bn) and self.world > 1:
+                ops.bn_combine(bl.stats, ns, bl.C)
+                dist.all_reduce(bl.stats[:2 * bl.C])
+                ns = 1
+                cnt = count * self.world
+            else:
+                cnt = count
             if cnt <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input "
                                  "size [%d values per channel]" % cnt)
@@ -304,7 +316,7 @@ class Engine:
             ops.bn_finalize(bl.stats, cnt, bm.weight.detach(), bm.bias.detach(),
                             bm.running_mean if track else None, bm.running_var if track else None,
                             bm.num_batches_tracked if track else None, bl.momentum, bl.eps, bl.mean,
-                            bl.invstd, bl.scale, bl.shift, bl.C)
+                            bl.invstd, bl.scale, bl.shift, bl.C, nslot=ns)
             return cnt
         ops.bn_eval_params(bm.weight.detach(), bm.bias.detach(), bm.running_mean, bm.running_var, bl.eps,
                            bl.scale, bl.shift, bl.C)
@@ -340,19 +352,19 @@ class Engine:
         else:
             g, ldg = gy, y.ld
         ops.bn_bwd_reduce(dout, out.ld, out.data if relu else None, out.ld, dropmask, y.H * y.W, y.data,
-                          y.ld, bl.mean, bl.invstd, g, ldg, bl.sums, y.M, y.C)
+                          y.ld, bl.mean, bl.invstd, g, ldg, bl.sums, y.M, y.C, nslot=ops.NSLOT)
         if y2 is not None:
             ops.bn_bwd_reduce(g, ldg, None, 0, None, y2.H * y2.W, y2.data, y2.ld, bl2.mean, bl2.invstd,
-                              None, 0, bl2.sums, y2.M, y2.C)
-            ops.bn_param_grads(bl2.sums, bl2.ggrad, bl2.bgrad, bl2.C)
-            self._sync(bl2.sums)
+                              None, 0, bl2.sums, y2.M, y2.C, nslot=ops.NSLOT)
+            ops.bn_param_grads(bl2.sums, bl2.ggrad, bl2.bgrad, bl2.C, nslot=ops.NSLOT)
+            self._sync(bl2.sums[:2 * bl2.C])
             gy2 = self.grad_of(y2)
             ops.bn_bwd_apply(g, ldg, y2.data, y2.ld, bl2.mean, bl2.invstd, bm2.weight.detach(), bl2.sums,
                              cnt, gy2, y2.ld, y2.M, y2.C)
             y2.ginit = True
             self._ready([bm2.weight, bm2.bias])
-        ops.bn_param_grads(bl.sums, bl.ggrad, bl.bgrad, bl.C)
-        self._sync(bl.sums)
+        ops.bn_param_grads(bl.sums, bl.ggrad, bl.bgrad, bl.C, nslot=ops.NSLOT)
+        self._sync(bl.sums[:2 * bl.C])
         ops.bn_bwd_apply(g, ldg, y.data, y.ld, bl.mean, bl.invstd, bm.weight.detach(), bl.sums, cnt, gy,
                          y.ld, y.M, y.C)
         y.ginit = True
@@ -370,7 +382,7 @@ class Engine:
         ops.stem_conv_fwd(x_nchw, w0, y0.data, N, H, W)
         bl = self.bns[l0[1]]
         if self.training and l0[1].training:
-            ops.channel_stats(y0.data, y0.ld, bl.stats, y0.M, 64)
+            ops.channel_stats(y0.data, y0.ld, bl.stats, y0.M, 64, nslot=ops.NSLOT)
         if self.training:
             def bwd():
                 ops.stem_conv_wgrad(x_nchw, y0.grad, self.grad_views[c0.weight], N, H, W)

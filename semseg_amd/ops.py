@@ -62,21 +62,29 @@ class PackedConv:
                                          _stream()), "conv_pack_weights")
 
 
-def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None, ldadd=0, stats=None):
+NSLOT = 8  # replicas of every fp64 statistics vector (see include/semseg_hip.h)
+
+
+def _scr(scratch):
+    return (None, 0) if scratch is None else (scratch.data_ptr(), scratch.numel())
+
+
+def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None, ldadd=0, stats=None,
+             nslot=1, scratch=None):
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
     _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
-                            pk.R, pk.S, stride, pad, dil, _p(bias), _p(add), ldadd, _p(stats),
-                            pk.tile_fwd, _stream()), "conv_fwd")
+                            pk.R, pk.S, stride, pad, dil, _p(bias), _p(add), ldadd, _p(stats), nslot,
+                            pk.tile_fwd, *_scr(scratch), _stream()), "conv_fwd")
     return Ho, Wo
 
 
-def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldadd=0):
+def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldadd=0, scratch=None):
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
     _ck(lib.semseg_conv_dgrad(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo,
                               pk.Co, pk.R, pk.S, stride, pad, dil, _p(add), ldadd, pk.tile_dgrad,
-                              _stream()), "conv_dgrad")
+                              *_scr(scratch), _stream()), "conv_dgrad")
 
 
 def wgrad_scratch_floats(Ci, Co, R, S):
@@ -105,12 +113,17 @@ def stem_conv_wgrad(x_nchw, dy, dw, N, H, W, accumulate=False):
 # ---------------------------------------------------------------------------------------------
 # batch norm family
 # ---------------------------------------------------------------------------------------------
-def channel_stats(x, ldx, stats, M, C):
-    _ck(lib.semseg_channel_stats(_p(x), ldx, _p(stats), M, C, _stream()), "channel_stats")
+def channel_stats(x, ldx, stats, M, C, nslot=1):
+    _ck(lib.semseg_channel_stats(_p(x), ldx, _p(stats), nslot, M, C, _stream()), "channel_stats")
 
 
-def bn_finalize(stats, count, gamma, beta, rm, rv, nbt, momentum, eps, mean, invstd, scale, shift, C):
-    _ck(lib.semseg_bn_finalize(_p(stats), float(count), _p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt),
+def bn_combine(stats, nslot, C):
+    _ck(lib.semseg_bn_combine(_p(stats), nslot, C, _stream()), "bn_combine")
+
+
+def bn_finalize(stats, count, gamma, beta, rm, rv, nbt, momentum, eps, mean, invstd, scale, shift, C,
+                nslot=1):
+    _ck(lib.semseg_bn_finalize(_p(stats), nslot, float(count), _p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt),
                                momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), C,
                                _stream()), "bn_finalize")
 
@@ -127,9 +140,10 @@ def bn_apply(y, ldy, scale, shift, out, ldout, M, C, HW, relu, y2=None, ldy2=0, 
                             _stream()), "bn_apply")
 
 
-def bn_bwd_reduce(dout, lddout, out, ldout, dropmask, HW, y, ldy, mean, invstd, g, ldg, sums, M, C):
+def bn_bwd_reduce(dout, lddout, out, ldout, dropmask, HW, y, ldy, mean, invstd, g, ldg, sums, M, C,
+                  nslot=1):
     _ck(lib.semseg_bn_bwd_reduce(_p(dout), lddout, _p(out), ldout, _p(dropmask), HW, _p(y), ldy,
-                                 _p(mean), _p(invstd), _p(g), ldg, _p(sums), M, C, _stream()),
+                                 _p(mean), _p(invstd), _p(g), ldg, _p(sums), nslot, M, C, _stream()),
         "bn_bwd_reduce")
 
 
@@ -138,8 +152,8 @@ def bn_bwd_apply(g, ldg, y, ldy, mean, invstd, gamma, sums, count, dy, lddy, M, 
                                 float(count), _p(dy), lddy, M, C, _stream()), "bn_bwd_apply")
 
 
-def bn_param_grads(sums, dgamma, dbeta, C, accumulate=False):
-    _ck(lib.semseg_bn_param_grads(_p(sums), _p(dgamma), _p(dbeta), C, int(accumulate), _stream()),
+def bn_param_grads(sums, dgamma, dbeta, C, accumulate=False, nslot=1):
+    _ck(lib.semseg_bn_param_grads(_p(sums), nslot, _p(dgamma), _p(dbeta), C, int(accumulate), _stream()),
         "bn_param_grads")
 
 
@@ -256,7 +270,7 @@ def gemm_rows(a_ptr, lda, bt_ptr, c_ptr, ldc, M, K, Nout, add_ptr=None, ldadd=0)
     implicit-GEMM kernel on raw device pointers."""
     tile = 128 if Nout >= 128 else 64
     _ck(lib.semseg_conv_fwd(a_ptr, lda, bt_ptr, c_ptr, ldc, 1, M, 1, K, M, 1, Nout, 1, 1, 1, 0, 1, None,
-                            add_ptr, ldadd, None, tile, _stream()), "gemm_rows")
+                            add_ptr, ldadd, None, 1, tile, None, 0, _stream()), "gemm_rows")
 
 
 def gemm_kmajor(x_ptr, ldx, y_ptr, ldy, out_ptr, scratch, K, Ci, Co, accumulate=False):

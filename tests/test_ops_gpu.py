@@ -90,10 +90,26 @@ def test_conv_fwd_dgrad_wgrad(case, report):
     scratch = torch.empty(ops.wgrad_scratch_floats(Ci, Co, k, k) * 4, device=DEV)
     ops.conv_wgrad(xv, ldx, dyb, ldy, dw, scratch, N, H, W, Ci, Co, k, k, s, p, d)
     e_w = relerr(dw, w64.grad)
-    report("conv %s fwd %.2e stats %.2e/%.2e bias+add %.2e dgrad %.2e wgrad %.2e"
-           % (case, e_f, e_s1, e_s2, e_b, e_d, e_w))
-    assert max(e_f, e_b, e_d, e_w) < 2e-5
-    assert max(e_s1, e_s2) < 1e-5
+    # split-K path (what small per-GPU batches take) with replicated statistics slots
+    NS = ops.NSLOT
+    st8 = torch.zeros(NS * 2 * Co, dtype=torch.float64, device=DEV)
+    yb3 = torch.zeros(N, Ho, Wo, ldy, device=DEV)
+    ops.conv_fwd(xv, ldx, pk, yb3, ldy, N, H, W, s, p, d, stats=st8, nslot=NS, scratch=scratch)
+    ops.bn_combine(st8, NS, Co)
+    e_sf = relerr(nchw(yb3[..., :Co]), y64)
+    e_ss = max(relerr(st8[:Co], y64.sum((0, 2, 3))), relerr(st8[Co:2 * Co], (y64 * y64).sum((0, 2, 3))))
+    yb4 = torch.zeros(N, Ho, Wo, Co, device=DEV)
+    ops.conv_fwd(xv, ldx, pk, yb4, Co, N, H, W, s, p, d, bias=bias.to(DEV), add=addb, ldadd=Co, scratch=scratch)
+    e_sb = relerr(nchw(yb4), ref2)
+    dxb2 = torch.randn(N, H, W, Ci, device=DEV)
+    base = dxb2.clone()
+    ops.conv_dgrad(dyb, ldy, pk, dxb2, Ci, N, H, W, s, p, d, add=dxb2, ldadd=Ci, scratch=scratch)
+    e_sd = relerr(nchw(dxb2 - base), x64.grad)
+    assert float(yb3[..., Co:].abs().max()) == 0.0
+    report("conv %s fwd %.2e stats %.2e/%.2e bias+add %.2e dgrad %.2e wgrad %.2e | split-K fwd %.2e stats %.2e "
+           "bias+add %.2e dgrad+add %.2e" % (case, e_f, e_s1, e_s2, e_b, e_d, e_w, e_sf, e_ss, e_sb, e_sd))
+    assert max(e_f, e_b, e_d, e_w, e_sf, e_sb, e_sd) < 2e-5
+    assert max(e_s1, e_s2, e_ss) < 1e-5
 
 
 def test_stem(report):
@@ -150,12 +166,13 @@ def test_bn_train_fwd_bwd(C, HW, mode, report):
 
     f = lambda t: t.detach().float().to(DEV)
     yd = nhwc(f(y))
-    stats = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
-    ops.channel_stats(yd, C, stats, M, C)
+    NS = ops.NSLOT
+    stats = torch.zeros(NS * 2 * C, dtype=torch.float64, device=DEV)
+    ops.channel_stats(yd, C, stats, M, C, nslot=NS)
     mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
     rmd, rvd = f(rm0), f(rv0)
     nbt = torch.zeros((), dtype=torch.int64, device=DEV)
-    ops.bn_finalize(stats, M, f(gamma), f(beta), rmd, rvd, nbt, 0.1, 1e-5, mean, invstd, scale, shift, C)
+    ops.bn_finalize(stats, M, f(gamma), f(beta), rmd, rvd, nbt, 0.1, 1e-5, mean, invstd, scale, shift, C, nslot=NS)
     outd = torch.empty(N, HW, HW, C, device=DEV)
     kw = {}
     if mode == "res":
@@ -174,13 +191,13 @@ def test_bn_train_fwd_bwd(C, HW, mode, report):
     assert int(nbt.item()) == 1
     # backward
     doutd = nhwc(f(dout))
-    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    sums = torch.zeros(NS * 2 * C, dtype=torch.float64, device=DEV)
     gd = torch.empty(N, HW, HW, C, device=DEV)
-    ops.bn_bwd_reduce(doutd, C, outd, C, dmd, HW * HW, yd, C, mean, invstd, gd, C, sums, M, C)
+    ops.bn_bwd_reduce(doutd, C, outd, C, dmd, HW * HW, yd, C, mean, invstd, gd, C, sums, M, C, nslot=NS)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_param_grads(sums, dg, db, C, nslot=NS)   # combines the replicas into slot 0
     dyd = torch.empty(N, HW, HW, C, device=DEV)
     ops.bn_bwd_apply(gd, C, yd, C, mean, invstd, f(gamma), sums, M, dyd, C, M, C)
-    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-    ops.bn_param_grads(sums, dg, db, C)
     e_dy, e_dg, e_db = relerr(nchw(dyd), y.grad), relerr(dg, gamma.grad), relerr(db, beta.grad)
     errs = [e_out, e_rm, e_rv, e_dy, e_dg, e_db]
     if mode == "res":
