@@ -39,7 +39,7 @@ for name, H, Ci, Co, k, s, p, d, cnt in SHAPES:
     dy = torch.zeros(N, Ho, Ho, ldy, device=dev); dy[..., :Co].normal_()
     dx = torch.empty(N, H, W, Ci, device=dev)
     dw = torch.empty(Co, Ci, k, k, device=dev)
-    stats = torch.zeros(2 * Co, dtype=torch.float64, device=dev)
+    stats8 = torch.zeros(2 * Co * ops.NSLOT, dtype=torch.float64, device=dev)
     fl = 2.0 * N * Ho * Ho * Co * Ci * k * k
     def timeit(fn, it=5):
         fn(); torch.cuda.synchronize()
@@ -48,8 +48,8 @@ for name, H, Ci, Co, k, s, p, d, cnt in SHAPES:
         for _ in range(it): fn()
         e_.record(); torch.cuda.synchronize()
         return s_.elapsed_time(e_) / it * 1e3
-    tf = timeit(lambda: ops.conv_fwd(x, Ci, pk, y, ldy, N, H, W, s, p, d, stats=stats))
-    td = timeit(lambda: ops.conv_dgrad(dy, ldy, pk, dx, Ci, N, H, W, s, p, d))
+    tf = timeit(lambda: ops.conv_fwd(x, Ci, pk, y, ldy, N, H, W, s, p, d, stats=stats8, nslot=ops.NSLOT, scratch=scratch))
+    td = timeit(lambda: ops.conv_dgrad(dy, ldy, pk, dx, Ci, N, H, W, s, p, d, scratch=scratch))
     tw = timeit(lambda: ops.conv_wgrad(x, Ci, dy, ldy, dw, scratch, N, H, W, Ci, Co, k, k, s, p, d))
     print("%-28s %8.1f | %8.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f" % (name, fl / 1e9, tf, fl / tf / 1e6, td, fl / td / 1e6, tw, fl / tw / 1e6))
     tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt

@@ -6,9 +6,7 @@ CSRC = os.path.join(ROOT, "semseg_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_variants")
 VARIANTS = {
     "base": [],
-    "abl1": ["-DCONV_ABL=1"],
-    "abl2": ["-DCONV_ABL=2"],
-    "abl3": ["-DCONV_ABL=3"],
+    "abl4_l1hit_loads": ["-DCONV_ABL=4"],
 }
 SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "optim.hip"]
 if sys.argv[1] == "build":

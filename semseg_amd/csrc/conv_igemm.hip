@@ -33,6 +33,11 @@ constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 co
 #define CONV_ABL 0
 #endif
 
+// Invalid gather lanes (padding taps, rows past M) read this zero line instead of being zeroed after
+// the load: a select on the loaded value would make the compiler wait for the load before the MFMA
+// block (measured: -13 % on every conv).
+__device__ __attribute__((aligned(16))) float g_zero_line[32] = {0};
+
 struct ConvArgs {
   const float* x;   // A source: activations (fwd) or output-gradient (dgrad), NHWC
   const float* w;   // packed B^T panel [Nout_pad][KT*32]
@@ -49,9 +54,12 @@ struct ConvArgs {
   int M;              // N*Hout*Wout
   int tiles_n;
   int stats_nslot;    // stats is [nslot][2*Nout]; tile_m % nslot picks the replica
-  int ksplit, kt_per; // split-K: workgroup (tile, ks) covers K-steps [ks*kt_per, (ks+1)*kt_per)
-  float* part;        // split-K partial slabs [ksplit][M][ldpart]
-  int ldpart;
+  // Split-K ("stream-K tail"): the first full_tiles tiles are computed whole; every later tile is
+  // cut into ksplit K-ranges, workgroup (tile, ks) covering K-steps [ks*kt_per, (ks+1)*kt_per) and
+  // writing a raw partial slab that splitk_epilogue_kernel reduces.  full_tiles == 0: all tiles split.
+  int full_tiles, ksplit, kt_per;
+  float* part;        // partial slabs [ksplit][M - tail_m0][ldpart]
+  int ldpart, tail_m0;
 };
 
 template <int BM, int BN, bool TR>
@@ -68,9 +76,16 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int ks = logical % p.ksplit;
-  const int tile = logical / p.ksplit;
+  int ks = 0, tile;
+  bool split = false;
+  if ((int)blockIdx.x < p.full_tiles) {
+    tile = xcd_remap(blockIdx.x, p.full_tiles);
+  } else {
+    const int u = xcd_remap(blockIdx.x - p.full_tiles, gridDim.x - p.full_tiles);
+    ks = u % p.ksplit;
+    tile = p.full_tiles + u / p.ksplit;
+    split = p.ksplit > 1;
+  }
   const int tile_n = tile % p.tiles_n;
   const int tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -79,8 +94,8 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
   const int nchunk = p.Kc / BK;
   const int KT_all = RS * nchunk;
   const size_t wK = (size_t)KT_all * BK;  // packed panel row length
-  const int kt0 = ks * p.kt_per;
-  const int KT = min(KT_all, kt0 + p.kt_per);  // this workgroup walks K-steps [kt0, KT)
+  const int kt0 = split ? ks * p.kt_per : 0;
+  const int KT = split ? min(KT_all, kt0 + p.kt_per) : KT_all;  // this workgroup walks [kt0, KT)
 
   // ---- per-thread staging assignment ----
   // The gather address of (row, tap) is separable: off = rowbase[row] + tapoff(tap) + channel, and
@@ -147,10 +162,8 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const bool ok = (a_mask[i] >> pf_tap) & 1u;
-      const int off = ok ? a_base[i] + toff : 0;  // row 0 of the tensor is always readable
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      ra[i] = ok ? v : z;
+      const float* src = ok ? p.x + (a_base[i] + toff) : g_zero_line;
+      ra[i] = *reinterpret_cast<const f32x4*>(src);
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
@@ -183,7 +196,9 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
     for (int i = 0; i < B_PER; ++i)
       *reinterpret_cast<f32x4*>(&B_[(lrow + 32 * i) * LDK + kq * 4]) = rb[i];
   };
-  auto compute = [&](const float* A_, const float* B_) {
+  // do_pf: issue the next tile's global loads after the first MFMA group, so their address VALU and
+  // issue slots hide in the shadow of this wave's own MFMAs instead of preceding them
+  auto compute = [&](const float* A_, const float* B_, bool do_pf, int kt_next) {
 #if CONV_PRIO
     __builtin_amdgcn_s_setprio(1);
 #endif
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
 #pragma unroll
           for (int j = 0; j < NREP; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+      if (k8 == 0 && do_pf) prefetch(kt_next);
     }
 #if CONV_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
     stage_store(As, Bs);
     __syncthreads();
 #endif
-    compute(As, Bs);
+    compute(As, Bs, false, 0);
 #if CONV_ABL == 1
     __syncthreads();
 #endif
@@ -238,8 +254,7 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
   for (int kt = kt0; kt < KT; ++kt) {
     float* cA = smem + (kt & 1) * STAGE;
     float* nA = smem + ((kt + 1) & 1) * STAGE;
-    if (kt + 1 < KT) prefetch(kt + 1);
-    compute(cA, cA + BM * LDK);
+    compute(cA, cA + BM * LDK, kt + 1 < KT, kt + 1);
     if (kt + 1 < KT) stage_store(nA, nA + BM * LDK);
     __syncthreads();
   }
@@ -247,15 +262,14 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
   for (int kt = kt0; kt < KT; ++kt) {
     stage_store(As, Bs);
     __syncthreads();
-    if (kt + 1 < KT) prefetch(kt + 1);
-    compute(As, Bs);
+    compute(As, Bs, kt + 1 < KT, kt + 1);
     __syncthreads();
   }
 #endif
 
-  if (p.ksplit > 1) {
+  if (split) {
     // raw partial tile; bias / add / statistics happen in splitk_epilogue_kernel
-    float* out = p.part + (size_t)ks * p.M * p.ldpart;
+    float* out = p.part + (size_t)ks * (p.M - p.tail_m0) * p.ldpart;
 #pragma unroll
     for (int j = 0; j < NREP; ++j) {
       const int col = n0 + wn * (BN / 2) + j * 32 + l31;
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          if (m < p.M) out[(size_t)m * p.ldpart + col] = acc[i][j][e];
+          if (m < p.M) out[(size_t)(m - p.tail_m0) * p.ldpart + col] = acc[i][j][e];
         }
     }
     return;
@@ -449,14 +463,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 
   f32x4 ry[Y_PER], rx[X_PER];
   const int tapoff = ((r * p.dil - p.pad) * p.Win + (s * p.dil - p.pad)) * p.ldx + ci0 + xc * 4;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto prefetch = [&](int kb) {
 #pragma unroll
     for (int i = 0; i < Y_PER; ++i) {
       const int m = kb + yr + i * YROWS;
-      const bool ok = m < kend;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)(ok ? m : kbeg) * p.lddy + co0 + yc * 4);
-      ry[i] = ok ? v : zero4;
+      const float* src = m < kend ? p.dy + (size_t)m * p.lddy + co0 + yc * 4 : g_zero_line;
+      ry[i] = *reinterpret_cast<const f32x4*>(src);
     }
 #pragma unroll
     for (int i = 0; i < X_PER; ++i) {
@@ -469,10 +481,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       const int ih = oh * p.stride + r * p.dil - p.pad;
       const int iw = ow * p.stride + s * p.dil - p.pad;
       const bool ok = m < kend && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
-      const int off = ok ? ((n * p.Hin + oh * p.stride) * p.Win + ow * p.stride) * p.ldx + tapoff
-                         : ci0 + xc * 4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);
-      rx[i] = ok ? v : zero4;
+      const float* src =
+          ok ? p.x + (((n * p.Hin + oh * p.stride) * p.Win + ow * p.stride) * p.ldx + tapoff) : g_zero_line;
+      rx[i] = *reinterpret_cast<const f32x4*>(src);
     }
   };
 
@@ -493,7 +504,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     for (int i = 0; i < X_PER; ++i)
       *reinterpret_cast<f32x4*>(&Xs[(xr + i * XROWS) * TN + xc * 4]) = rx[i];
     __syncthreads();
-    if (kb + 32 < kend) prefetch(kb + 32);
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
       float a[MREP], bb[NREP];
@@ -506,6 +516,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+      if (kp == 3 && kb + 32 < kend) prefetch(kb + 32);
     }
     __syncthreads();
   }
@@ -619,24 +630,43 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   p.tiles_n = (a.Nout + BN - 1) / BN;
   const int tiles = tiles_m * p.tiles_n;
   const int KT = a.R * a.S * (a.Kc / BK);
-  // Split K when the tile grid cannot fill 256 CUs (small per-GPU batch): each (tile, ks) workgroup
+  // Split K (a) for every tile when the grid cannot fill 256 CUs (small per-GPU batch), (b) for the
+  // last partial wave of a large grid ("stream-K tail": 900 tiles on 256 CUs = 3.5 rounds, the half
+  // round is cut into K-slices so it costs ~0.6 instead of 1 round).  Each (tile, ks) workgroup
   // writes a raw partial slab, splitk_epilogue_kernel reduces + applies the epilogue.
-  int ksplit = 1;
+  const int P = 256;
+  int ksplit = 1, full_tiles = tiles, tail_mt = 0;
   p.ldpart = p.tiles_n * BN;
-  // (the epilogue kernel stores 16-byte lanes: y rows must be 16-byte aligned and padded to 4 channels)
-  if (scratch && tiles < 384 && (a.ldy & 3) == 0 && a.ldy >= ((a.Nout + 3) & ~3)) {
+  const bool can_split = scratch && (a.ldy & 3) == 0 && a.ldy >= ((a.Nout + 3) & ~3) && KT >= 8;
+  if (can_split && tiles < 384) {
     ksplit = (640 + tiles - 1) / tiles;
     if (ksplit > KT / 4) ksplit = KT / 4;
     if (ksplit > 16) ksplit = 16;
-    const size_t slab = (size_t)a.M * p.ldpart;
-    while (ksplit > 1 && slab * ksplit > scratch_floats) --ksplit;
-    if (ksplit < 1) ksplit = 1;
+    full_tiles = 0;
+    tail_mt = tiles_m;
+  } else if (can_split) {
+    const int rem = tiles % P;
+    if (rem != 0 && rem <= 208) {
+      tail_mt = (rem + p.tiles_n - 1) / p.tiles_n;
+      if (tail_mt > tiles_m) tail_mt = tiles_m;
+      full_tiles = tiles - tail_mt * p.tiles_n;
+      ksplit = 16;
+      while (ksplit > 1 && ksplit > KT / 4) ksplit >>= 1;
+      if (ksplit == 1) { full_tiles = tiles; tail_mt = 0; }
+    }
   }
+  p.tail_m0 = (tiles_m - tail_mt) * 128;
+  if (ksplit > 1) {
+    const size_t slab = (size_t)(a.M - p.tail_m0) * p.ldpart;
+    while (ksplit > 1 && slab * ksplit > scratch_floats) --ksplit;
+  }
+  if (ksplit <= 1) { ksplit = 1; full_tiles = tiles; tail_mt = 0; p.tail_m0 = 0; }
   p.kt_per = (KT + ksplit - 1) / ksplit;
   ksplit = (KT + p.kt_per - 1) / p.kt_per;
   p.ksplit = ksplit;
+  p.full_tiles = ksplit > 1 ? full_tiles : tiles;
   p.part = scratch;
-  const int grid = tiles * ksplit;
+  const int grid = p.full_tiles + (tiles - p.full_tiles) * ksplit;
   if (BN == 128) {
     if (transposed)
       conv_igemm_kernel<128, 128, true><<<grid, 256, 0, stream>>>(p);
@@ -649,17 +679,19 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
       conv_igemm_kernel<128, 64, false><<<grid, 256, 0, stream>>>(p);
   }
   if (ksplit > 1) {
+    const int Mt = a.M - p.tail_m0;  // rows covered by split tiles
     const int CV = (a.Nout + 3) / 4;
     int tpr = 1;
     while (tpr * 2 <= CV && tpr * 2 <= 256) tpr *= 2;
     const int rpb = 256 / tpr, gx = (CV + tpr - 1) / tpr;
-    int gy = (a.M + rpb - 1) / rpb;
+    int gy = (Mt + rpb - 1) / rpb;
     int cap = 1024 / gx;
     if (cap < 1) cap = 1;
     if (gy > cap) gy = cap;
-    splitk_epilogue_kernel<<<dim3(gx, gy), 256, 0, stream>>>(scratch, ksplit, p.ldpart, a.y, a.ldy, a.bias,
-                                                            a.add, a.ldadd, a.stats, a.stats_nslot, a.M,
-                                                            a.Nout, tpr, rpb);
+    splitk_epilogue_kernel<<<dim3(gx, gy), 256, 0, stream>>>(
+        scratch, ksplit, p.ldpart, a.y + (size_t)p.tail_m0 * a.ldy, a.ldy, a.bias,
+        a.add ? a.add + (size_t)p.tail_m0 * a.ldadd : nullptr, a.ldadd, a.stats, a.stats_nslot, Mt, a.Nout,
+        tpr, rpb);
   }
   return semseg_launch_status();
 }
@@ -718,7 +750,19 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
   a.div_wo = make_fastdiv(Wo);
   const int tiles = a.tiles_co * a.tiles_ci * RS;
   const int ksteps = (M + 31) / 32;
-  int ksplit = (1536 + tiles - 1) / tiles;
+  // aim at one full residency round (256 CUs x 3 workgroups) without spilling into a second one
+  int ksplit = 768 / tiles;
+  if (tiles > 384) {
+    // more than half a round of tiles already: pick the K split whose workgroup count fills whole
+    // residency rounds best (e.g. cls.0: 1152 tiles -> x2 = 2304 = 3 rounds exactly)
+    double best = 0.0;
+    ksplit = 1;
+    for (int ks = 1; ks <= 8; ++ks) {
+      const int wgs = tiles * ks;
+      const double eff = (double)wgs / (double)(((wgs + 767) / 768) * 768);
+      if (eff > best + 0.02) { best = eff; ksplit = ks; }
+    }
+  }
   if (ksplit > ksteps / 8) ksplit = ksteps / 8;
   if (ksplit < 1) ksplit = 1;
   const size_t slab = (size_t)a.Co_pad * RS * Ci;

@@ -35,6 +35,7 @@ CONV_CASES = [
     (2, 9, 9, 512, 150, 1, 1, 0, 1),
     (3, 7, 7, 2048, 512, 1, 1, 0, 1),
     (1, 12, 12, 512, 64, 3, 1, 1, 1),
+    (7, 60, 60, 64, 256, 3, 1, 2, 2),     # 197 m-tiles x 2 = 394 tiles: stream-K tail path
 ]
 
 
