@@ -355,22 +355,40 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
       for (int k = 0; k < 4; ++k) bv[k] = (c + k < Nout) ? bias[c + k] : 0.f;
     }
     const size_t slab = (size_t)M * ldpart;
-    for (int m = blockIdx.y * rpb + tr; m < M; m += gridDim.y * rpb) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(part + (size_t)m * ldpart + c);
-      for (int k = 1; k < ksplit; ++k)
-        a += *reinterpret_cast<const f32x4*>(part + k * slab + (size_t)m * ldpart + c);
-      a += bv;
-      if (add) {
+    constexpr int U = 2;
+    const int step = gridDim.y * rpb;
+    for (int mb = blockIdx.y * rpb + tr; mb < M; mb += U * step) {
+      f32x4 a[U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (c + k < Nout) a[k] += add[(size_t)m * ldadd + c + k];
+      for (int u = 0; u < U; ++u) {
+        const int m = mb + u * step < M ? mb + u * step : mb;
+        a[u] = *reinterpret_cast<const f32x4*>(part + (size_t)m * ldpart + c);
       }
-      *reinterpret_cast<f32x4*>(y + (size_t)m * ldy + c) = a;
+      for (int k = 1; k < ksplit; ++k) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const double d = (double)a[k];
-        v[k] += d;
-        v[4 + k] += d * d;
+        for (int u = 0; u < U; ++u) {
+          const int m = mb + u * step < M ? mb + u * step : mb;
+          a[u] += *reinterpret_cast<const f32x4*>(part + k * slab + (size_t)m * ldpart + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int m = mb + u * step;
+        if (m < M) {
+          f32x4 r = a[u] + bv;
+          if (add) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c + k < Nout) r[k] += add[(size_t)m * ldadd + c + k];
+          }
+          *reinterpret_cast<f32x4*>(y + (size_t)m * ldy + c) = r;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const double d = (double)r[k];
+            v[k] += d;
+            v[4 + k] += d * d;
+          }
+        }
       }
     }
   }
@@ -684,8 +702,8 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     int tpr = 1;
     while (tpr * 2 <= CV && tpr * 2 <= 256) tpr *= 2;
     const int rpb = 256 / tpr, gx = (CV + tpr - 1) / tpr;
-    int gy = (Mt + rpb - 1) / rpb;
-    int cap = 1024 / gx;
+    int gy = (Mt + 2 * rpb - 1) / (2 * rpb);
+    int cap = 512 / gx;
     if (cap < 1) cap = 1;
     if (gy > cap) gy = cap;
     splitk_epilogue_kernel<<<dim3(gx, gy), 256, 0, stream>>>(

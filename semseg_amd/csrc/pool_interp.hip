@@ -2,8 +2,9 @@
 //  * MaxPool2d(3, stride 2, pad 1)            — model/resnet.py:115 (layer0.9 via model/pspnet.py:46)
 //  * AdaptiveAvgPool2d(bin)                   — model/pspnet.py:14 (PPM)
 //  * bilinear interpolate, align_corners=True — model/pspnet.py:25, model/psanet.py:61,78-79,97
-// Backward kernels are gather-formulated (each thread owns an input-gradient element) so they are
-// deterministic and need no atomics.
+// Backward kernels are gather-formulated (each thread owns an input-gradient element).  Only the
+// tiny PPM tensors (a few low-res cells with map-sized windows) split their window over several
+// workgroups and merge with fp32 atomics.
 #include "common.h"
 #include "../../include/semseg_hip.h"
 
@@ -120,13 +121,26 @@ __global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(const float* __r
   const int w0 = (j * W) / bin, w1 = ((j + 1) * W + bin - 1) / bin;
   const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (c >= C) return;
+  // the window's rows are split over gridDim.z workgroups (big windows: bin 1 = whole map) and merged
+  // with fp32 atomics into the pre-zeroed output
+  const int nz = gridDim.z;
+  const int rows = h1 - h0;
+  const int per = (rows + nz - 1) / nz;
+  const int hs = h0 + blockIdx.z * per, he = min(h1, hs + per);
+  if (hs >= he) return;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int h = h0; h < h1; ++h)
+  for (int h = hs; h < he; ++h)
     for (int w = w0; w < w1; ++w)
       acc += *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + h) * W + w) * ldx + c);
   const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
   acc *= inv;
-  *reinterpret_cast<f32x4*>(y + pb.out_off[b] + ((size_t)(n * bin + i) * bin + j) * C + c) = acc;
+  float* o = y + pb.out_off[b] + ((size_t)(n * bin + i) * bin + j) * C + c;
+  if (nz == 1) {
+    *reinterpret_cast<f32x4*>(o) = acc;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(o + k, acc[k]);
+  }
 }
 
 // dx[n,h,w,c] = base[n,h,w,c] + sum_bins sum_{cells containing (h,w)} dpool[cell]/area
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
   if (c < C) {
     const int nw = ow_hi - ow_lo + 1;
     const int cnt = (oh_hi - oh_lo + 1) * nw;
-    for (int q = part; q < cnt; q += 4) {
+    for (int q = part + 4 * blockIdx.z; q < cnt; q += 4 * gridDim.z) {
       const int oh = oh_lo + q / nw, ow = ow_lo + q % nw;
       int h0, h1, w0, w1;
       float lh, lw;
@@ -247,7 +261,13 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
   __syncthreads();
   if (part == 0 && c < C) {
     acc = red[lanec] + red[64 + lanec] + red[128 + lanec] + red[192 + lanec];
-    *reinterpret_cast<f32x4*>(dx + (size_t)pix * lddx + c) = acc;
+    float* o = dx + (size_t)pix * lddx + c;
+    if (gridDim.z == 1) {
+      *reinterpret_cast<f32x4*>(o) = acc;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(o + k, acc[k]);
+    }
   }
 }
 
@@ -318,7 +338,15 @@ int semseg_adaptive_avgpool_fwd(const float* x, int ldx, float* y, const int* bi
   if (!x || !y || (C & 3) || (ldx & 3)) return SEMSEG_EINVAL;
   PoolBins pb;
   if (make_bins(bins, nbins, N, C, pb)) return SEMSEG_EINVAL;
-  dim3 grid(N * pb.cell_start[nbins], (C / 4 + 255) / 256);
+  const int cells = N * pb.cell_start[nbins];
+  int nz = 1;
+  if (cells * ((C / 4 + 255) / 256) < 512 && H >= 16) nz = 8;
+  if (nz > 1) {
+    size_t tot = 0;
+    for (int b = 0; b < nbins; ++b) tot += (size_t)N * bins[b] * bins[b] * C;
+    if (hipMemsetAsync(y, 0, tot * sizeof(float), stream) != hipSuccess) return SEMSEG_ELAUNCH;
+  }
+  dim3 grid(cells, (C / 4 + 255) / 256, nz);
   adaptive_pool_fwd_kernel<<<grid, 256, 0, stream>>>(x, ldx, y, pb, N, H, W, C);
   return semseg_launch_status();
 }
@@ -345,7 +373,18 @@ int semseg_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H
 int semseg_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hi, int Wi,
                         int Ho, int Wo, int C, hipStream_t stream) {
   if (!dy || !dx || (C & 3) || (lddx & 3) || (lddy & 3)) return SEMSEG_EINVAL;
-  dim3 grid(N * Hi * Wi, (C / 4 + 63) / 64);
+  // few low-res pixels with huge footprints (PPM bins): split the footprint over gridDim.z and
+  // merge with fp32 atomics into the zeroed gradient (only valid for a dense dx, lddx == C)
+  int nz = 1;
+  const int blocks = N * Hi * Wi * ((C / 4 + 63) / 64);
+  if (blocks < 1024 && lddx == C && Ho * Wo >= 64 * Hi * Wi) {
+    nz = 1024 / blocks;
+    if (nz > 64) nz = 64;
+    if (nz < 1) nz = 1;
+  }
+  if (nz > 1 && hipMemsetAsync(dx, 0, (size_t)N * Hi * Wi * C * sizeof(float), stream) != hipSuccess)
+    return SEMSEG_ELAUNCH;
+  dim3 grid(N * Hi * Wi, (C / 4 + 63) / 64, nz);
   bilinear_bwd_kernel<<<grid, 256, 0, stream>>>(dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C,
                                                ac_scale(Hi, Ho), ac_scale(Wi, Wo));
   return semseg_launch_status();
