@@ -128,7 +128,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("SEMSEG_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -168,7 +169,7 @@ def main():
         for e in tr.engines.values():
             e.ktimer = kt
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
@@ -176,11 +177,11 @@ def main():
         _, main_loss, aux_loss = tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
         it += 1
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.time() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -212,7 +213,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.layers, args.classes, args.size)
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -126,7 +126,7 @@ int semseg_ce_head_fwd(const float* scores, int ld, const long long* label, floa
 int semseg_ce_head_bwd(const float* scores, int ld, const long long* label, const float* lse,
                        const double* acc2, const float* grad_loss, float grad_mul, float* dscores,
                        int lddz, int accumulate, int N, int h, int w, int H, int W, int C,
-                       int ignore_index, hipStream_t stream);
+                       int ignore_index, float* scratch, size_t scratch_floats, hipStream_t stream);
 
 /* ---- PSA head on the engine's pixel-major layout (model/psanet.py:53-98).
  * psamask_nhwc: attention map [N, H*W, taps(ldm)] <-> affinity rows aff[n, q, p] (lda >= H*W), same

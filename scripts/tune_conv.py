@@ -5,8 +5,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "semseg_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_variants")
 VARIANTS = {
-    "base": [],
-    "abl4_l1hit_loads": ["-DCONV_ABL=4"],
+    "abl3_1wg": ["-DCONV_ABL=3", "-DCONV_LDSPAD=16384"],
+    "abl3_2wg": ["-DCONV_ABL=3", "-DCONV_LDSPAD=8192"],
+    "base_1wg": ["-DCONV_LDSPAD=16384"],
+    "dbuf_1wg": ["-DCONV_DBUF=1", "-DCONV_LDSPAD=8192"],
+    "base_2wg": ["-DCONV_LDSPAD=8192"],
 }
 SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "optim.hip"]
 if sys.argv[1] == "build":
@@ -22,5 +25,5 @@ else:
     for tag in VARIANTS:
         env = dict(os.environ, SEMSEG_HIP_LIB=os.path.join(OUT, "lib_%s.so" % tag))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "conv_bench.py")], env=env, capture_output=True, text=True)
-        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("l3 conv1", "l3 conv2", "l3 conv3", "l4 conv2", "cls.0", "weighted"))]
+        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("stem3", "l3 conv1", "l3 conv2", "l3 conv3", "l4 conv", "cls.0", "aux.0", "weighted"))]
         print("==", tag); print("\n".join(lines)); sys.stdout.flush()

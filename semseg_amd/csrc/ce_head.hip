@@ -166,6 +166,125 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z
   }
 }
 
+// ---- cell-based backward (4x less work than the gather form: every hi-res pixel is visited once) ----
+// A "cell" is the square between four adjacent low-res points.  Kernel A: one workgroup per cell walks
+// the hi-res pixels whose interpolation base lies in the cell and accumulates their contribution to the
+// cell's four corners; kernel B sums, for every low-res point, the matching corners of its <= 4 cells.
+// Deterministic (no atomics).  cellbuf: [N][ch][cw][4][CP] floats, CP = roundup4(C).
+template <int CG>
+__global__ __launch_bounds__(256) void ce_bwd_cell_kernel(const float* __restrict__ z, int ld,
+                                                          const long long* __restrict__ label,
+                                                          const float* __restrict__ lse,
+                                                          float* __restrict__ cellbuf, int N, int h,
+                                                          int w, int H, int W, int C, int CP,
+                                                          int ignore_index, float sh, float sw) {
+  constexpr int PARTS = 256 / CG;
+  __shared__ f32x4 red[4][256];
+  const int ch = max(h - 1, 1), cw = max(w - 1, 1);
+  int b = blockIdx.x;
+  const int cc = b % cw; b /= cw;
+  const int cr = b % ch;
+  const int n = b / ch;
+  const int cg = threadIdx.x % CG, part = threadIdx.x / CG;
+  const int c = cg * 4;
+  // conservative hi-res range of the cell; exact membership is re-checked per pixel
+  int oh_lo = 0, oh_hi = H - 1, ow_lo = 0, ow_hi = W - 1;
+  if (sh > 0.f) { oh_lo = (int)floorf((float)cr / sh) - 1; oh_hi = (int)ceilf((float)(cr + 1) / sh) + 1; }
+  if (sw > 0.f) { ow_lo = (int)floorf((float)cc / sw) - 1; ow_hi = (int)ceilf((float)(cc + 1) / sw) + 1; }
+  if (cr == ch - 1) oh_hi = H - 1;
+  if (cc == cw - 1) ow_hi = W - 1;
+  oh_lo = max(oh_lo, 0); ow_lo = max(ow_lo, 0);
+  oh_hi = min(oh_hi, H - 1); ow_hi = min(ow_hi, W - 1);
+  const int nw = ow_hi - ow_lo + 1;
+  const int cnt = (oh_hi - oh_lo + 1) * nw;
+  f32x4 a[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float* bz = z + (size_t)n * h * w * ld + c;
+    for (int q = part; q < cnt; q += PARTS) {
+      const int oh = oh_lo + q / nw, ow = ow_lo + q % nw;
+      int h0, h1, w0, w1;
+      float lh, lw;
+      src_index(oh, h, sh, h0, h1, lh);
+      src_index(ow, w, sw, w0, w1, lw);
+      if (min(h0, ch - 1) != cr || min(w0, cw - 1) != cc) continue;
+      const size_t px = ((size_t)n * H + oh) * W + ow;
+      const long long y = label[px];
+      if (y == (long long)ignore_index || y < 0 || y >= C) continue;
+      const float a00 = (1.f - lh) * (1.f - lw), a01 = (1.f - lh) * lw, a10 = lh * (1.f - lw), a11 = lh * lw;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(bz + ((size_t)h0 * w + w0) * ld) * a00 +
+                      *reinterpret_cast<const f32x4*>(bz + ((size_t)h0 * w + w1) * ld) * a01 +
+                      *reinterpret_cast<const f32x4*>(bz + ((size_t)h1 * w + w0) * ld) * a10 +
+                      *reinterpret_cast<const f32x4*>(bz + ((size_t)h1 * w + w1) * ld) * a11;
+      const float l = lse[px];
+      f32x4 pk;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pk[k] = (c + k < C) ? __expf(v[k] - l) : 0.f;
+        if ((long long)(c + k) == y) pk[k] -= 1.f;
+      }
+      // weights onto the cell's corner rows cr, cr+1 / cols cc, cc+1 (static register indexing;
+      // h1 == h0 / w1 == w0 on the last low-res row / column)
+      const float rw0 = (h0 == cr ? 1.f - lh : 0.f) + (h1 == cr ? lh : 0.f);
+      const float rw1 = (h0 == cr + 1 ? 1.f - lh : 0.f) + (h1 == cr + 1 ? lh : 0.f);
+      const float cw0 = (w0 == cc ? 1.f - lw : 0.f) + (w1 == cc ? lw : 0.f);
+      const float cw1 = (w0 == cc + 1 ? 1.f - lw : 0.f) + (w1 == cc + 1 ? lw : 0.f);
+      a[0] += pk * (rw0 * cw0);
+      a[1] += pk * (rw0 * cw1);
+      a[2] += pk * (rw1 * cw0);
+      a[3] += pk * (rw1 * cw1);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[q][threadIdx.x] = a[q];
+  __syncthreads();
+  if (part == 0 && c < CP) {
+    float* o = cellbuf + ((((size_t)n * ch + cr) * cw + cc) * 4) * CP + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 r = red[q][cg];
+      for (int pp = 1; pp < PARTS; ++pp) r += red[q][pp * CG + cg];
+      *reinterpret_cast<f32x4*>(o + (size_t)q * CP) = r;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_gather_cells_kernel(const float* __restrict__ cellbuf,
+                                                                  const double* __restrict__ acc,
+                                                                  const float* __restrict__ gloss,
+                                                                  float gmul, float* __restrict__ dz,
+                                                                  int lddz, int accumulate, int N,
+                                                                  int h, int w, int CP) {
+  const int ch = max(h - 1, 1), cw = max(w - 1, 1);
+  const int CV = CP >> 2;
+  const size_t total = (size_t)N * h * w * CV;
+  float scale = gmul / (float)acc[1];
+  if (gloss) scale *= gloss[0];
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int c = (int)(idx % CV) * 4;
+    size_t t = idx / CV;
+    const int j = (int)(t % w); t /= w;
+    const int i = (int)(t % h);
+    const int n = (int)(t / h);
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    // cells (cr, cc) with corner (i - cr, j - cc) in {0,1}^2
+    for (int dr = 0; dr < 2; ++dr) {
+      const int cr = i - dr;
+      if (cr < 0 || cr >= ch) continue;
+      for (int dc = 0; dc < 2; ++dc) {
+        const int cc = j - dc;
+        if (cc < 0 || cc >= cw) continue;
+        r += *reinterpret_cast<const f32x4*>(cellbuf + ((((size_t)n * ch + cr) * cw + cc) * 4 + dr * 2 + dc) * CP + c);
+      }
+    }
+    r *= scale;
+    float* o = dz + (((size_t)n * h + i) * w + j) * lddz + c;
+    if (accumulate) r += *reinterpret_cast<const f32x4*>(o);
+    *reinterpret_cast<f32x4*>(o) = r;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -187,13 +306,34 @@ int semseg_ce_head_fwd(const float* scores, int ld, const long long* label, floa
 int semseg_ce_head_bwd(const float* scores, int ld, const long long* label, const float* lse,
                        const double* acc2, const float* grad_loss, float grad_mul, float* dscores,
                        int lddz, int accumulate, int N, int h, int w, int H, int W, int C,
-                       int ignore_index, hipStream_t stream) {
+                       int ignore_index, float* scratch, size_t scratch_floats, hipStream_t stream) {
   if (!scores || !label || !lse || !acc2 || !dscores || (ld & 3) || (lddz & 3) ||
       ld < ((C + 3) & ~3) || lddz < ((C + 3) & ~3))
     return SEMSEG_EINVAL;
   const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const int cv = (C + 3) / 4;
+  const int CP = cv * 4;
+  const int ch = h > 1 ? h - 1 : 1, cw = w > 1 ? w - 1 : 1;
+  const size_t need = (size_t)N * ch * cw * 4 * CP;
+  if (scratch && need <= scratch_floats && cv <= 128) {
+    const int cells = N * ch * cw;
+#define CE_CELL(CG)                                                                                 \
+  ce_bwd_cell_kernel<CG><<<cells, 256, 0, stream>>>(scores, ld, label, lse, scratch, N, h, w, H, W, C, \
+                                                    CP, ignore_index, sh, sw)
+    if (cv <= 8) CE_CELL(8);
+    else if (cv <= 16) CE_CELL(16);
+    else if (cv <= 32) CE_CELL(32);
+    else if (cv <= 64) CE_CELL(64);
+    else CE_CELL(128);
+#undef CE_CELL
+    size_t tot = (size_t)N * h * w * cv;
+    size_t g = (tot + 255) / 256;
+    if (g > 4096) g = 4096;
+    ce_bwd_gather_cells_kernel<<<(int)g, 256, 0, stream>>>(scratch, acc2, grad_loss, grad_mul, dscores, lddz,
+                                                          accumulate, N, h, w, CP);
+    return semseg_launch_status();
+  }
   const int grid = N * h * w;
 #define CE_BWD(CG)                                                                                  \
   ce_bwd_kernel<CG><<<grid, 256, 0, stream>>>(scores, ld, label, lse, acc2, grad_loss, grad_mul,   \

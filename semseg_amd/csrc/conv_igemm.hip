@@ -63,11 +63,17 @@ struct ConvArgs {
 };
 
 template <int BM, int BN, bool TR>
-__global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArgs p) {
-  constexpr int MREP = BM / 64, NREP = BN / 64;
-  constexpr int A_PER = BM / 32, B_PER = BN / 32;
+__global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const ConvArgs p) {
+  // BM/64 x 2 waves, each a 64 x (BN/2) sub-tile of 32x32 MFMA blocks
+  constexpr int NT = BM * 2;                 // threads
+  constexpr int RSTEP = NT / 8;              // tile rows staged per pass (8 lanes x 16 B per row)
+  constexpr int MREP = 2, NREP = BN / 64;
+  constexpr int A_PER = BM / RSTEP, B_PER = BN / RSTEP;
   constexpr int STAGE = (BM + BN) * LDK;
-  __shared__ __attribute__((aligned(16))) float smem[(CONV_DBUF ? 2 : 1) * STAGE];
+#ifndef CONV_LDSPAD
+#define CONV_LDSPAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) float smem[(CONV_DBUF ? 2 : 1) * STAGE + CONV_LDSPAD];
   float* As = smem;
   float* Bs = smem + BM * LDK;
 
@@ -102,12 +108,12 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
   // its validity is one bit of a per-row tap mask, both computed once here; the K loop then walks
   // (chunk, r, s) with scalar counters only (no divisions, no divergent branches around the loads).
   const int kq = tid & 7;     // which float4 of the 32-float K-step
-  const int lrow = tid >> 3;  // 0..31
+  const int lrow = tid >> 3;  // 0..RSTEP-1
   int a_base[A_PER];
   unsigned a_mask[A_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
-    const int m = m0 + lrow + 32 * i;
+    const int m = m0 + lrow + RSTEP * i;
     const bool rok = m < p.M;
     const int mm = rok ? m : 0;
     const int hw = p.Hout * p.Wout;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
   }
   const float* bptr[B_PER];
 #pragma unroll
-  for (int i = 0; i < B_PER; ++i) bptr[i] = p.w + (size_t)(n0 + lrow + 32 * i) * wK + kq * 4;
+  for (int i = 0; i < B_PER; ++i) bptr[i] = p.w + (size_t)(n0 + lrow + RSTEP * i) * wK + kq * 4;
 
   f32x4 ra[A_PER], rb[B_PER];
   // scalar K-walk state of the NEXT tile to prefetch
@@ -191,10 +197,10 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
   auto stage_store = [&](float* A_, float* B_) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i)
-      *reinterpret_cast<f32x4*>(&A_[(lrow + 32 * i) * LDK + kq * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&A_[(lrow + RSTEP * i) * LDK + kq * 4]) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
-      *reinterpret_cast<f32x4*>(&B_[(lrow + 32 * i) * LDK + kq * 4]) = rb[i];
+      *reinterpret_cast<f32x4*>(&B_[(lrow + RSTEP * i) * LDK + kq * 4]) = rb[i];
   };
   // do_pf: issue the next tile's global loads after the first MFMA group, so their address VALU and
   // issue slots hide in the shadow of this wave's own MFMAs instead of preceding them
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
         a[i] = *reinterpret_cast<const f32x4*>(
-            &A_[(wm * (BM / 2) + i * 32 + l31) * LDK + k8 * 8 + lhi * 4]);
+            &A_[(wm * 64 + i * 32 + l31) * LDK + k8 * 8 + lhi * 4]);
 #pragma unroll
       for (int j = 0; j < NREP; ++j)
         b[j] = *reinterpret_cast<const f32x4*>(
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
       for (int i = 0; i < MREP; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
           if (m < p.M) out[(size_t)(m - p.tail_m0) * p.ldpart + col] = acc[i][j][e];
         }
     }
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
   }
 
   // ---- epilogue: store, optional bias / residual add, optional fp64 channel statistics ----
-  double* red = reinterpret_cast<double*>(smem);  // [2 (wm)][BN][2]
+  double* red = reinterpret_cast<double*>(smem);  // [BM/64 (wm)][BN][2]
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
     const int lcol = wn * (BN / 2) + j * 32 + l31;
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
     for (int i = 0; i < MREP; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
         const int m = m0 + row;
         if (m < p.M && cok) {
           float v = acc[i][j][e] + bv;
@@ -323,8 +329,12 @@ __global__ __launch_bounds__(256, CONV_OCC) void conv_igemm_kernel(const ConvArg
     if (tid < BN) {
       const int col = n0 + tid;
       if (col < p.Nout) {
-        const double s1 = red[(0 * BN + tid) * 2 + 0] + red[(1 * BN + tid) * 2 + 0];
-        const double s2 = red[(0 * BN + tid) * 2 + 1] + red[(1 * BN + tid) * 2 + 1];
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < BM / 64; ++r) {
+          s1 += red[(r * BN + tid) * 2 + 0];
+          s2 += red[(r * BN + tid) * 2 + 1];
+        }
         double* st = p.stats + (size_t)(tile_m % p.stats_nslot) * 2 * p.Nout;
         atomic_add_f64(&st[col], s1);
         atomic_add_f64(&st[p.Nout + col], s2);
@@ -641,9 +651,15 @@ int semseg_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_dgrad, 
   return semseg_launch_status();
 }
 
+#ifndef CONV_BM256
+#define CONV_BM256 0
+#endif
 static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratch,
                        size_t scratch_floats, hipStream_t stream) {
-  const int tiles_m = (a.M + 127) / 128;
+  // 256-row tiles (8 waves) halve the weight-panel traffic per MFMA; used when the grid is large
+  const bool big = CONV_BM256 && BN == 128 && ((a.M + 255) / 256) * ((a.Nout + 127) / 128) >= 512;
+  const int BMr = big ? 256 : 128;
+  const int tiles_m = (a.M + BMr - 1) / BMr;
   ConvArgs p = a;
   p.tiles_n = (a.Nout + BN - 1) / BN;
   const int tiles = tiles_m * p.tiles_n;
@@ -673,7 +689,7 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
       if (ksplit == 1) { full_tiles = tiles; tail_mt = 0; }
     }
   }
-  p.tail_m0 = (tiles_m - tail_mt) * 128;
+  p.tail_m0 = (tiles_m - tail_mt) * BMr;
   if (ksplit > 1) {
     const size_t slab = (size_t)(a.M - p.tail_m0) * p.ldpart;
     while (ksplit > 1 && slab * ksplit > scratch_floats) --ksplit;
@@ -685,7 +701,12 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   p.full_tiles = ksplit > 1 ? full_tiles : tiles;
   p.part = scratch;
   const int grid = p.full_tiles + (tiles - p.full_tiles) * ksplit;
-  if (BN == 128) {
+  if (big) {
+    if (transposed)
+      conv_igemm_kernel<256, 128, true><<<grid, 512, 0, stream>>>(p);
+    else
+      conv_igemm_kernel<256, 128, false><<<grid, 512, 0, stream>>>(p);
+  } else if (BN == 128) {
     if (transposed)
       conv_igemm_kernel<128, 128, true><<<grid, 256, 0, stream>>>(p);
     else

@@ -214,10 +214,10 @@ def ce_head_fwd(scores, ld, label, lse, pred, acc2, loss, N, h, w, H, W, C, igno
 
 
 def ce_head_bwd(scores, ld, label, lse, acc2, grad_loss, grad_mul, dscores, lddz, accumulate, N, h, w,
-                H, W, C, ignore_index):
+                H, W, C, ignore_index, scratch=None):
     _ck(lib.semseg_ce_head_bwd(_p(scores), ld, _p(label), _p(lse), _p(acc2), _p(grad_loss),
                                float(grad_mul), _p(dscores), lddz, int(accumulate), N, h, w, H, W, C,
-                               ignore_index, _stream()), "ce_head_bwd")
+                               ignore_index, *_scr(scratch), _stream()), "ce_head_bwd")
 
 
 def sgd_step(w, g, mom, n, lr, momentum, weight_decay, grad_scale=1.0, first_step=False, lr_dev=None):

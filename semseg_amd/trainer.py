@@ -8,6 +8,8 @@ DistributedDataParallel plays at tool/train.py:157), with SyncBN statistics on t
 
 `poly_learning_rate` restates util/util.py:34-37.
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -29,6 +31,7 @@ class Trainer:
         self.ignore_index = ignore_index
         self.device = next(model.parameters()).device
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.dist_on = self.world > 1 or (os.environ.get("SEMSEG_FORCE_DIST") == "1" and dist.is_initialized())
         self.sync_bn = sync_bn
         self.engines = {}
         self.steps = 0
@@ -36,7 +39,7 @@ class Trainer:
         self.g_main = torch.ones(1, device=self.device)
         self.g_aux = torch.full((1,), float(aux_weight), device=self.device)
         self.bucket_elems = bucket_mb * 1024 * 1024 // 4
-        self.grad_group = dist.new_group() if self.world > 1 else None
+        self.grad_group = dist.new_group() if self.dist_on else None
         self.timers = None
 
     # parameters -> one flat buffer (offsets 16-byte aligned, same layout as Engine.flat_grad)
@@ -69,9 +72,9 @@ class Trainer:
         e = self.engines.get(key)
         if e is None:
             e = Engine(self.model, x.shape[0], x.shape[2], x.shape[3], True, self.model.kind)
-            e.force_sync_bn = self.sync_bn and self.world > 1
+            e.force_sync_bn = self.sync_bn and self.dist_on
             assert e.flat_grad.numel() == self.total
-            if self.world > 1:
+            if self.dist_on:
                 self._make_buckets(e)
                 e.grads_ready_hook = lambda plist, e=e: self._on_ready(e, plist)
             self.engines[key] = e
@@ -112,11 +115,12 @@ class Trainer:
         lr = self.base_lr if lr is None else lr
         e = self.engine(x)
         pred, main_loss, aux_loss = e.forward_train(x, y, self.ignore_index)
-        if self.world > 1:
+        if self.dist_on:
             e._pending = [len(ps) for _, _, ps in e._buckets]
             e._works = []
         e.backward(self.g_main, self.g_aux)
-        if self.world > 1:
+        if self.dist_on:
+            assert all(c == 0 for c in e._pending), "a gradient bucket never completed"
             for w in e._works:
                 w.wait()
         first = self.steps == 0

@@ -328,6 +328,13 @@ def test_ce_head(C, h, H, report):
     ops.ce_head_bwd(zb, ld, labd, lse, acc, gl, 1.0, dz, ld, False, N, h, w, H, W, C, 255)
     e_l = abs(float(lossd.item()) - float(loss)) / abs(float(loss))
     e_g = relerr(nchw(dz[..., :C]), z.grad)
+    # cell-based backward (the path the engine takes: scratch given)
+    dz2 = torch.full((N, h, w, ld), 7.0, device=DEV)
+    scr = torch.empty(8 * 1024 * 1024, device=DEV)
+    ops.ce_head_bwd(zb, ld, labd, lse, acc, gl, 1.0, dz2, ld, False, N, h, w, H, W, C, 255, scratch=scr)
+    e_g2 = relerr(nchw(dz2[..., :C]), z.grad)
+    assert e_g2 < 2e-5, e_g2
+    assert float(dz2[..., C:ops.roundup(C, 4)].abs().max()) == 0.0 if ops.roundup(C, 4) > C else True
     agree = float((pred.cpu() == up.argmax(1)).float().mean())
     padz = float(dz[..., C:ops.roundup(C, 4)].abs().max()) if ops.roundup(C, 4) > C else 0.0
     report("ce head C=%d loss %.2e grad %.2e argmax-agree %.5f cnt %d/%d" %
