@@ -207,7 +207,20 @@ def main():
                                                       PEAK_F32_MFMA_TFLOPS, 4),
         }
         if kt is not None:
-            out["roofline"] = kt.roofline(PEAK_F32_MFMA_TFLOPS)
+            roof = kt.roofline(PEAK_F32_MFMA_TFLOPS)
+            # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3
+            # cannot run inside this process; the file records the exact commands and corrections)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")))["kernels"]
+                key = roof["kernel"].split("+")[0].split("(")[0].replace(" ", "")
+                for k, v in pmc.items():
+                    if k.replace(" ", "") == key:
+                        roof["traffic"] = v["hbm_bytes_per_launch"]
+                        roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_pmc_per_kernel.json)"
+                        roof["mfma_busy_frac_pmc"] = v.get("mfma_busy_frac")
+            except Exception:
+                pass
+            out["roofline"] = roof
             out["kernel_families"] = kt.summary()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.layers, args.classes, args.size)
