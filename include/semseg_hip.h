@@ -146,6 +146,32 @@ int semseg_transpose_batched(const float* in, int ldi, long long batch_stride_in
                              int ldo, long long batch_stride_out, int batch, int R, int C,
                              hipStream_t stream);
 
+/* ---- test-time pipeline kept on the device (tool/test.py:122-204, tool/demo.py:106-189):
+ * resize_linear_hwc = cv2.resize(float32 HWC, INTER_LINEAR) (test.py:201); crop_normalize_flip =
+ * mean-padded crop + ToTensor/normalise + [x, flip(x)] batch (test.py:123-132,156,171; origins are
+ * (y,x) pairs in unpadded coordinates, on the device); softmax_flip_accumulate = softmax + flip average
+ * + canvas/count accumulation (test.py:139-141,172-173); resize_accumulate_chw = /count, un-pad,
+ * cv2.resize to the original size, sum over scales (test.py:175-177,203); argmax_chw (test.py:204). */
+int semseg_resize_linear_hwc(const float* src, int Hs, int Ws, float* dst, int Hd, int Wd, int C,
+                             hipStream_t stream);
+int semseg_crop_normalize_flip(const float* img_hwc, int H, int W, const int* origins_dev, int K,
+                               int crop_h, int crop_w, const float* mean3, const float* std3,
+                               float* out_nchw, hipStream_t stream);
+int semseg_softmax_flip_accumulate(const float* logits_nchw, const int* pos_dev, int K, int C,
+                                   int crop_h, int crop_w, float* canvas_chw, float* count, int Hc,
+                                   int Wc, hipStream_t stream);
+int semseg_resize_accumulate_chw(const float* canvas_chw, const float* count, int Hc, int Wc, int y0,
+                                 int x0, int Hs, int Ws, float* dst_chw, int Hd, int Wd, int C,
+                                 float weight, hipStream_t stream);
+int semseg_argmax_chw(const float* prob_chw, long long* out, int C, int H, int W, hipStream_t stream);
+
+/* ---- intersectionAndUnionGPU (util/util.py:55-67; tool/train.py:286,375): one pass over int64
+ * prediction/target, hist3K = 3*K uint64 scratch, outputs fp32 [K] each like torch.histc returns. */
+int semseg_intersection_and_union(const long long* pred, const long long* target, size_t n, int K,
+                                  int ignore_index, unsigned long long* hist3K,
+                                  float* area_intersection, float* area_union, float* area_target,
+                                  hipStream_t stream);
+
 /* ---- torch.optim.SGD step (tool/train.py:140,276) over a flat range. */
 int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, float lr, const float* lr_dev,
                     float momentum, float weight_decay, float grad_scale, int first_step,

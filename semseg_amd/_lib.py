@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("SEMSEG_HIP_LIB") or os.path.join(HERE, "csrc", "libse
 
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
-    "size_t": ctypes.c_size_t, "hipStream_t": ctypes.c_void_p, "long long": ctypes.c_longlong,
+    "size_t": ctypes.c_size_t, "hipStream_t": ctypes.c_void_p, "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong,
 }
 
 

@@ -277,3 +277,32 @@ def gemm_kmajor(x_ptr, ldx, y_ptr, ldy, out_ptr, scratch, K, Ci, Co, accumulate=
     """out[Co][Ci] (=|+=) sum_k y[k][co] * x[k][ci] — the weight-gradient kernel as a K-major GEMM."""
     _ck(lib.semseg_conv_wgrad(x_ptr, ldx, y_ptr, ldy, out_ptr, _p(scratch), scratch.numel(), 1, K, 1, Ci,
                               K, 1, Co, 1, 1, 1, 0, 1, int(accumulate), _stream()), "gemm_kmajor")
+
+
+# ---------------------------------------------------------------------------------------------
+# test-time pipeline (tool/test.py:122-204) kept on the device
+# ---------------------------------------------------------------------------------------------
+def resize_linear_hwc(src, Hs, Ws, dst, Hd, Wd, C):
+    _ck(lib.semseg_resize_linear_hwc(_p(src), Hs, Ws, _p(dst), Hd, Wd, C, _stream()), "resize_linear_hwc")
+
+
+def crop_normalize_flip(img, H, W, origins_dev, K, ch, cw, mean, std, out):
+    import ctypes
+    m = (ctypes.c_float * 3)(*mean)
+    s_ = (ctypes.c_float * 3)(*std)
+    _ck(lib.semseg_crop_normalize_flip(_p(img), H, W, _p(origins_dev), K, ch, cw, ctypes.addressof(m),
+                                       ctypes.addressof(s_), _p(out), _stream()), "crop_normalize_flip")
+
+
+def softmax_flip_accumulate(logits, pos_dev, K, C, ch, cw, canvas, count, Hc, Wc):
+    _ck(lib.semseg_softmax_flip_accumulate(_p(logits), _p(pos_dev), K, C, ch, cw, _p(canvas), _p(count), Hc,
+                                           Wc, _stream()), "softmax_flip_accumulate")
+
+
+def resize_accumulate_chw(canvas, count, Hc, Wc, y0, x0, Hs, Ws, dst, Hd, Wd, C, weight):
+    _ck(lib.semseg_resize_accumulate_chw(_p(canvas), _p(count), Hc, Wc, y0, x0, Hs, Ws, _p(dst), Hd, Wd, C,
+                                         float(weight), _stream()), "resize_accumulate_chw")
+
+
+def argmax_chw(prob, out, C, H, W):
+    _ck(lib.semseg_argmax_chw(_p(prob), _p(out), C, H, W, _stream()), "argmax_chw")

@@ -505,3 +505,27 @@ def test_lib_psa_functional_dropin(report):
     with pytest.raises(RuntimeError):
         PF.psa_mask(torch.randn(1, 49, 4, 4))
     report("lib.psa.functional.psa_mask == reference golden vectors (%d cases), checks ok" % len(keys))
+
+
+def test_intersection_and_union(report):
+    """util/util.py:40-52 (numpy form) is the oracle for the device kernel (util/util.py:55-67 form)."""
+    import numpy as np
+    from semseg_amd.metrics import intersectionAndUnionGPU
+    K = 150
+    g = torch.Generator().manual_seed(8)
+    out = torch.randint(0, K, (4, 97, 113), generator=g)
+    tgt = torch.randint(0, K, (4, 97, 113), generator=g)
+    tgt[torch.rand(4, 97, 113, generator=g) < 0.1] = 255
+    same = torch.rand(4, 97, 113, generator=g) < 0.5
+    out[same] = tgt[same].clamp(max=K - 1)
+    o, t = out.numpy().reshape(-1).copy(), tgt.numpy().reshape(-1)
+    o[np.where(t == 255)[0]] = 255
+    inter = o[np.where(o == t)[0]]
+    ai, _ = np.histogram(inter, bins=np.arange(K + 1))
+    ao, _ = np.histogram(o, bins=np.arange(K + 1))
+    at, _ = np.histogram(t, bins=np.arange(K + 1))
+    i, u, tt = intersectionAndUnionGPU(out.cuda(), tgt.cuda(), K, 255)
+    assert np.array_equal(i.cpu().numpy(), ai.astype(np.float32))
+    assert np.array_equal(u.cpu().numpy(), (ao + at - ai).astype(np.float32))
+    assert np.array_equal(tt.cpu().numpy(), at.astype(np.float32))
+    report("intersectionAndUnionGPU == numpy reference (exact)")
