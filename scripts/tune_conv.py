@@ -5,13 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "semseg_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_variants")
 VARIANTS = {
-    "abl3_1wg": ["-DCONV_ABL=3", "-DCONV_LDSPAD=16384"],
-    "abl3_2wg": ["-DCONV_ABL=3", "-DCONV_LDSPAD=8192"],
-    "base_1wg": ["-DCONV_LDSPAD=16384"],
-    "dbuf_1wg": ["-DCONV_DBUF=1", "-DCONV_LDSPAD=8192"],
-    "base_2wg": ["-DCONV_LDSPAD=8192"],
+    "base": [],
+    "voff_onfly": ["-DCONV_VOFF_ONFLY=1"],
 }
-SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "optim.hip"]
+SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "infer.hip", "optim.hip"]
 if sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     procs = []

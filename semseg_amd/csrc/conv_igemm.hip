@@ -11,6 +11,8 @@
 //
 // Tile: 256 threads = 4 waves (2x2), block tile BM x BN x 32, each wave (BM/2)x(BN/2) as
 // 32x32 MFMA blocks; global->register prefetch of K-step t+1 overlaps the MFMAs of step t.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/semseg_hip.h"
 
@@ -62,7 +64,11 @@ struct ConvArgs {
   int ldpart, tail_m0;
 };
 
-template <int BM, int BN, bool TR>
+// RS_T == 0: generic tap walk with global loads.  RS_T == 1 / 9 (1x1 / 3x3): the tap loop is unrolled
+// and the gather uses buffer loads with per-(row,tap) byte offsets precomputed in VGPRs (invalid taps
+// carry an out-of-range offset, which the buffer unit returns as 0) plus one scalar offset per K-step —
+// no per-K-step address VALU between the MFMAs at all.
+template <int BM, int BN, bool TR, int RS_T>
 __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const ConvArgs p) {
   // BM/64 x 2 waves, each a 64 x (BN/2) sub-tile of 32x32 MFMA blocks
   constexpr int NT = BM * 2;                 // threads
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
   };
   // do_pf: issue the next tile's global loads after the first MFMA group, so their address VALU and
   // issue slots hide in the shadow of this wave's own MFMAs instead of preceding them
-  auto compute = [&](const float* A_, const float* B_, bool do_pf, int kt_next) {
+  auto compute = [&](const float* A_, const float* B_, auto&& issue_next) {
 #if CONV_PRIO
     __builtin_amdgcn_s_setprio(1);
 #endif
@@ -233,13 +239,93 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
 #pragma unroll
           for (int j = 0; j < NREP; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
-      if (k8 == 0 && do_pf) prefetch(kt_next);
+      if (k8 == 0) issue_next();
     }
 #if CONV_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
   };
 
+  if constexpr (RS_T > 0) {
+    // ---------------- buffer-load path: unrolled taps, zero address VALU in the K loop -------------
+    constexpr unsigned OOB = 0x80000000u;          // >= num_records: the buffer unit returns 0
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x80000000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x80000000, 0x00020000);
+#ifndef CONV_VOFF_ONFLY
+#define CONV_VOFF_ONFLY 1
+#endif
+    // per-tap byte offsets (uniform -> SGPRs)
+    int toffs[RS_T];
+#pragma unroll
+    for (int t = 0; t < RS_T; ++t) {
+      const int r = t / p.S, s_ = t - (t / p.S) * p.S;
+      if (!TR)
+        toffs[t] = (r * p.dil * p.Win + s_ * p.dil) * p.ldx * 4;
+      else
+        toffs[t] = -(((r * p.dil) / p.stride) * p.Win + (s_ * p.dil) / p.stride) * p.ldx * 4;
+    }
+    unsigned voffB[B_PER];
+#if CONV_VOFF_ONFLY
+    unsigned baseA[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) baseA[i] = (unsigned)(a_base[i] * 4);
+#else
+    unsigned voffA[A_PER][RS_T];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+#pragma unroll
+      for (int t = 0; t < RS_T; ++t)
+        voffA[i][t] = ((a_mask[i] >> t) & 1u) ? (unsigned)(a_base[i] * 4 + toffs[t]) : OOB;
+#endif
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      voffB[i] = (unsigned)(((size_t)(n0 + lrow + RSTEP * i) * wK + kq * 4) * 4);
+    const int c_begin = kt0 / RS_T, c_end = KT / RS_T;
+    auto load_tile = [&](auto tapc, int c) {
+      constexpr int t = decltype(tapc)::value;
+      const int so_a = c * (BK * 4);
+      const int so_b = (c * RS_T + t) * (BK * 4);
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+#if CONV_VOFF_ONFLY
+        const unsigned vo = ((a_mask[i] >> t) & 1u) ? baseA[i] + (unsigned)toffs[t] : OOB;
+#else
+        const unsigned vo = voffA[i][t];
+#endif
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, vo, so_a, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i)
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw_, voffB[i], so_b, 0));
+    };
+    auto step = [&](auto tapc, int c) {
+      constexpr int t = decltype(tapc)::value;
+      stage_store(As, Bs);
+      __syncthreads();
+      compute(As, Bs, [&] {
+        if constexpr (t + 1 < RS_T) {
+          load_tile(std::integral_constant<int, t + 1>{}, c);
+        } else {
+          if (c + 1 < c_end) load_tile(std::integral_constant<int, 0>{}, c + 1);
+        }
+      });
+      __syncthreads();
+    };
+    if (c_begin < c_end) load_tile(std::integral_constant<int, 0>{}, c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+      step(std::integral_constant<int, 0>{}, c);
+      if constexpr (RS_T == 9) {
+        step(std::integral_constant<int, 1>{}, c);
+        step(std::integral_constant<int, 2>{}, c);
+        step(std::integral_constant<int, 3>{}, c);
+        step(std::integral_constant<int, 4>{}, c);
+        step(std::integral_constant<int, 5>{}, c);
+        step(std::integral_constant<int, 6>{}, c);
+        step(std::integral_constant<int, 7>{}, c);
+        step(std::integral_constant<int, 8>{}, c);
+      }
+    }
+  } else {
   prefetch(kt0);
 #if CONV_ABL
   stage_store(As, Bs);
@@ -249,7 +335,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
     stage_store(As, Bs);
     __syncthreads();
 #endif
-    compute(As, Bs, false, 0);
+    compute(As, Bs, [] {});
 #if CONV_ABL == 1
     __syncthreads();
 #endif
@@ -260,7 +346,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
   for (int kt = kt0; kt < KT; ++kt) {
     float* cA = smem + (kt & 1) * STAGE;
     float* nA = smem + ((kt + 1) & 1) * STAGE;
-    compute(cA, cA + BM * LDK, kt + 1 < KT, kt + 1);
+    compute(cA, cA + BM * LDK, [&] { if (kt + 1 < KT) prefetch(kt + 1); });
     if (kt + 1 < KT) stage_store(nA, nA + BM * LDK);
     __syncthreads();
   }
@@ -268,10 +354,11 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
   for (int kt = kt0; kt < KT; ++kt) {
     stage_store(As, Bs);
     __syncthreads();
-    compute(As, Bs, kt + 1 < KT, kt + 1);
+    compute(As, Bs, [&] { if (kt + 1 < KT) prefetch(kt + 1); });
     __syncthreads();
   }
 #endif
+  }  // RS_T == 0
 
   if (split) {
     // raw partial tile; bias / add / statistics happen in splitk_epilogue_kernel
@@ -491,6 +578,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 
   f32x4 ry[Y_PER], rx[X_PER];
   const int tapoff = ((r * p.dil - p.pad) * p.Win + (s * p.dil - p.pad)) * p.ldx + ci0 + xc * 4;
+  // (buffer loads were measured neutral-to-negative here: the pixel decode VALU remains either way)
   auto prefetch = [&](int kb) {
 #pragma unroll
     for (int i = 0; i < Y_PER; ++i) {
@@ -696,27 +784,39 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   }
   if (ksplit <= 1) { ksplit = 1; full_tiles = tiles; tail_mt = 0; p.tail_m0 = 0; }
   p.kt_per = (KT + ksplit - 1) / ksplit;
+  {
+    const int RSr = a.R * a.S;  // split on channel-chunk boundaries (whole tap groups)
+    p.kt_per = (p.kt_per + RSr - 1) / RSr * RSr;
+  }
   ksplit = (KT + p.kt_per - 1) / p.kt_per;
   p.ksplit = ksplit;
   p.full_tiles = ksplit > 1 ? full_tiles : tiles;
   p.part = scratch;
   const int grid = p.full_tiles + (tiles - p.full_tiles) * ksplit;
+  // buffer-load kernels need 1x1 / 3x3 taps, split points on chunk boundaries and < 2 GB operands
+#ifndef CONV_BUFLOAD
+#define CONV_BUFLOAD 1
+#endif
+  const int RSv = a.R * a.S;
+  const size_t x_bytes = (size_t)a.N * a.Hin * a.Win * a.ldx * 4, w_bytes = (size_t)p.tiles_n * BN * KT * BK * 4;
+  const bool bl = CONV_BUFLOAD && !big && (RSv == 1 || RSv == 9) && (p.kt_per % RSv == 0) &&
+                  x_bytes < 0x7FFF0000ull && w_bytes < 0x7FFF0000ull;
+#define LAUNCH_CONV(BM_, BN_, TR_, RS_) conv_igemm_kernel<BM_, BN_, TR_, RS_><<<grid, BM_ * 2, 0, stream>>>(p)
+#define LAUNCH_RS(BM_, BN_, TR_)                                   \
+  do {                                                             \
+    if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);             \
+    else if (bl) LAUNCH_CONV(BM_, BN_, TR_, 1);                    \
+    else LAUNCH_CONV(BM_, BN_, TR_, 0);                            \
+  } while (0)
   if (big) {
-    if (transposed)
-      conv_igemm_kernel<256, 128, true><<<grid, 512, 0, stream>>>(p);
-    else
-      conv_igemm_kernel<256, 128, false><<<grid, 512, 0, stream>>>(p);
+    if (transposed) LAUNCH_CONV(256, 128, true, 0); else LAUNCH_CONV(256, 128, false, 0);
   } else if (BN == 128) {
-    if (transposed)
-      conv_igemm_kernel<128, 128, true><<<grid, 256, 0, stream>>>(p);
-    else
-      conv_igemm_kernel<128, 128, false><<<grid, 256, 0, stream>>>(p);
+    if (transposed) LAUNCH_RS(128, 128, true); else LAUNCH_RS(128, 128, false);
   } else {
-    if (transposed)
-      conv_igemm_kernel<128, 64, true><<<grid, 256, 0, stream>>>(p);
-    else
-      conv_igemm_kernel<128, 64, false><<<grid, 256, 0, stream>>>(p);
+    if (transposed) LAUNCH_RS(128, 64, true); else LAUNCH_RS(128, 64, false);
   }
+#undef LAUNCH_RS
+#undef LAUNCH_CONV
   if (ksplit > 1) {
     const int Mt = a.M - p.tail_m0;  // rows covered by split tiles
     const int CV = (a.Nout + 3) / 4;
@@ -775,6 +875,7 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
     return SEMSEG_EINVAL;
   const int RS = R * S;
   const int M = N * Ho * Wo;
+  if ((size_t)N * H * W * ldx >= 0x7FFF0000ull) return SEMSEG_EINVAL;  // 32-bit element offsets
   const bool big = (Ci % 128 == 0) && (Co >= 128);
   const int TM = big ? 128 : 64, TN = big ? 128 : 64;
   WgradArgs a;
