@@ -51,6 +51,10 @@ class _Lib:
                 raise RuntimeError(
                     "libsemseg_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; "
                     "g.build()'` or `python -m semseg_amd.build`. There is no CPU fallback." % LIB_PATH)
+            # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): it must be the one already
+            # resident when our library resolves its HIP dependency, otherwise two HIP runtimes end up in
+            # the process and every launch on a torch stream fails
+            import torch  # noqa: F401
             self._dll = ctypes.CDLL(LIB_PATH)
             for name, (ret, args) in parse_header().items():
                 f = getattr(self._dll, name)  # AttributeError if the symbol is missing
