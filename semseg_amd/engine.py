@@ -229,7 +229,7 @@ class Engine:
         if out is None:
             ld = cl.Co if cl.Co % 64 == 0 else ops.roundup(cl.Co, 128)
             out = self.act(x.N, Ho, Wo, cl.Co, ld=ld, tag="conv")
-        ev = self._t0("conv_igemm_kernel<128,%d,false>(+splitk_epilogue)" % cl.pk.tile_fwd, 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
+        ev = self._t0("conv_igemm_kernel<128,%d,false,%d>(+splitk_epilogue)" % (cl.pk.tile_fwd, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
         ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
                      bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats,
                      nslot=ops.NSLOT, scratch=self.scratch())
@@ -259,7 +259,7 @@ class Engine:
             ready.append(m.bias)
         if x.name != "input":
             gx = self.grad_of(x)
-            ev = self._t0("conv_igemm_kernel<128,%d,true>(+splitk_epilogue)" % cl.pk.tile_dgrad, flops)
+            ev = self._t0("conv_igemm_kernel<128,%d,true,%d>(+splitk_epilogue)" % (cl.pk.tile_dgrad, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), flops)
             ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
                            add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
             self._t1(ev)
