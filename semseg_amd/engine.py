@@ -136,6 +136,10 @@ class Engine:
         self.grads_ready_hook = None  # callable(param_list) fired as parameter gradients complete
         self.weights_version = None
         self.ktimer = None
+        self.side_wgrad = os.environ.get("SEMSEG_SIDE_WGRAD", "1") == "1"
+        self._side = None
+        self._scr2 = None
+        self._side_used = False
         self._mod_ids = tuple(id(m) for m in model.modules())
 
     def params_stale(self):
@@ -238,14 +242,12 @@ class Engine:
             self.tape.append(lambda: self._conv_bwd(x, out, cl, m))
         return out
 
-    def _conv_bwd(self, x, y, cl, m):
+    def _wgrad(self, x, y, cl, m, scratch):
         dy = y.grad
-        assert dy is not None
-        self.scratch()
         flops = 2.0 * y.M * cl.Co * cl.Ci * cl.R * cl.S
         big = cl.Ci % 128 == 0 and cl.Co >= 128
         ev = self._t0("conv_wgrad_kernel<%d,%d>+reduce" % ((128, 128) if big else (64, 64)), flops)
-        ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, self.wgrad_scratch, x.N, x.H, x.W, cl.Ci,
+        ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
                        cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil)
         self._t1(ev)
         ready = [m.weight]
@@ -257,6 +259,26 @@ class Engine:
             ops.channel_stats(dy, y.ld, st, y.M, C4)
             ops.bn_param_grads(st, self._dummy(C4), cl.bgrad, cl.Co)
             ready.append(m.bias)
+        self._ready(ready)
+
+    def _conv_bwd(self, x, y, cl, m):
+        dy = y.grad
+        assert dy is not None
+        flops = 2.0 * y.M * cl.Co * cl.Ci * cl.R * cl.S
+        # Weight gradients are off the critical path of backward (nothing downstream reads them until
+        # the optimizer / the gradient all-reduce).  When this conv's grid cannot fill the GPU on its
+        # own (small per-GPU batch) it runs on a side HIP stream, concurrently with the data-gradient /
+        # BatchNorm chain; both operands (x, dy) are final by now and stay untouched until the join at
+        # the end of backward().
+        side = self.side_wgrad and y.M * cl.Co < 512 * 128 * 128
+        if side:
+            st = self._side_stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                self._wgrad(x, y, cl, m, self._scratch2())
+            self._side_used = True
+        else:
+            self._wgrad(x, y, cl, m, self.scratch())
         if x.name != "input":
             gx = self.grad_of(x)
             ev = self._t0("conv_igemm_kernel<128,%d,true,%d>(+splitk_epilogue)" % (cl.pk.tile_dgrad, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), flops)
@@ -264,7 +286,16 @@ class Engine:
                            add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
             self._t1(ev)
             x.ginit = True
-        self._ready(ready)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def _scratch2(self):
+        if self._scr2 is None:
+            self._scr2 = torch.empty(32 * 1024 * 1024, dtype=F32, device=self.device)
+        return self._scr2
 
     def scratch(self):
         """256 MB arena for split-K partial slabs (conv fwd/dgrad at small batch, every wgrad)."""
@@ -596,6 +627,9 @@ class Engine:
         self.ce_bwd(self._rec_aux, gaux)
         for fn in reversed(self.tape):
             fn()
+        if self._side_used:
+            torch.cuda.current_stream().wait_stream(self._side)   # join the weight-gradient stream
+            self._side_used = False
 
     def _reset_grad_flags(self):
         pass  # Act objects are rebuilt every forward, so ginit starts False
