@@ -808,9 +808,12 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     else if (bl) LAUNCH_CONV(BM_, BN_, TR_, 1);                    \
     else LAUNCH_CONV(BM_, BN_, TR_, 0);                            \
   } while (0)
+#if CONV_BM256
   if (big) {
     if (transposed) LAUNCH_CONV(256, 128, true, 0); else LAUNCH_CONV(256, 128, false, 0);
-  } else if (BN == 128) {
+  } else
+#endif
+  if (BN == 128) {
     if (transposed) LAUNCH_RS(128, 128, true); else LAUNCH_RS(128, 128, false);
   } else {
     if (transposed) LAUNCH_RS(128, 64, true); else LAUNCH_RS(128, 64, false);
