@@ -48,7 +48,8 @@ for name, H, Ci, Co, k, s, p, d, cnt in SHAPES:
         for _ in range(it): fn()
         e_.record(); torch.cuda.synchronize()
         return s_.elapsed_time(e_) / it * 1e3
-    tf = timeit(lambda: ops.conv_fwd(x, Ci, pk, y, ldy, N, H, W, s, p, d, stats=stats8, nslot=ops.NSLOT, scratch=scratch))
+    st_arg = None if os.environ.get('NOSTATS') else stats8
+    tf = timeit(lambda: ops.conv_fwd(x, Ci, pk, y, ldy, N, H, W, s, p, d, stats=st_arg, nslot=ops.NSLOT, scratch=scratch))
     td = timeit(lambda: ops.conv_dgrad(dy, ldy, pk, dx, Ci, N, H, W, s, p, d, scratch=scratch))
     tw = timeit(lambda: ops.conv_wgrad(x, Ci, dy, ldy, dw, scratch, N, H, W, Ci, Co, k, k, s, p, d))
     print("%-28s %8.1f | %8.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f" % (name, fl / 1e9, tf, fl / tf / 1e6, td, fl / td / 1e6, tw, fl / tw / 1e6))

@@ -6,7 +6,9 @@ CSRC = os.path.join(ROOT, "semseg_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_variants")
 VARIANTS = {
     "base": [],
-    "voff_onfly": ["-DCONV_VOFF_ONFLY=1"],
+    "stagger1": ["-DCONV_STAGGER=1"],
+    "stagger2": ["-DCONV_STAGGER=2"],
+    "stagger4": ["-DCONV_STAGGER=4"],
 }
 SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "infer.hip", "optim.hip"]
 if sys.argv[1] == "build":
@@ -22,5 +24,5 @@ else:
     for tag in VARIANTS:
         env = dict(os.environ, SEMSEG_HIP_LIB=os.path.join(OUT, "lib_%s.so" % tag))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "conv_bench.py")], env=env, capture_output=True, text=True)
-        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("stem3", "l3 conv1", "l3 conv2", "l3 conv3", "l4 conv", "cls.0", "aux.0", "weighted"))]
+        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("l1 conv", "l3 conv1", "l3 conv2", "l3 conv3", "l4 conv3", "weighted"))]
         print("==", tag); print("\n".join(lines)); sys.stdout.flush()

@@ -35,6 +35,22 @@ constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 co
 #define CONV_ABL 0
 #endif
 
+// exact n / d for 0 <= n < 2^31 by one 64-bit multiply: q = (n * mul) >> sh
+struct FastDiv {
+  unsigned mul, sh;
+};
+inline FastDiv make_fastdiv(int d) {
+  int l = 0;
+  while ((1LL << l) < d) ++l;
+  FastDiv f;
+  f.sh = 31 + l;
+  f.mul = (unsigned)(((1ULL << f.sh) + (unsigned long long)d - 1) / (unsigned long long)d);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) {
+  return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh);
+}
+
 // Invalid gather lanes (padding taps, rows past M) read this zero line instead of being zeroed after
 // the load: a select on the loaded value would make the compiler wait for the load before the MFMA
 // block (measured: -13 % on every conv).
@@ -62,6 +78,7 @@ struct ConvArgs {
   int full_tiles, ksplit, kt_per;
   float* part;        // partial slabs [ksplit][M - tail_m0][ldpart]
   int ldpart, tail_m0;
+  FastDiv div_hw, div_w, div_tn, div_ks;  // Hout*Wout, Wout, tiles_n, ksplit
 };
 
 // RS_T == 0: generic tap walk with global loads.  RS_T == 1 / 9 (1x1 / 3x3): the tap loop is unrolled
@@ -79,7 +96,9 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
 #ifndef CONV_LDSPAD
 #define CONV_LDSPAD 0
 #endif
-  __shared__ __attribute__((aligned(16))) float smem[(CONV_DBUF ? 2 : 1) * STAGE + CONV_LDSPAD];
+  constexpr int EPI = (NT / 64) * 64 * LDK;  // per-wave transposition slabs of the epilogue
+  constexpr int SMEM_F = ((CONV_DBUF ? 2 : 1) * STAGE > EPI ? (CONV_DBUF ? 2 : 1) * STAGE : EPI) + CONV_LDSPAD;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
   float* As = smem;
   float* Bs = smem + BM * LDK;
 
@@ -88,18 +107,30 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
 
+#ifndef CONV_STAGGER
+#define CONV_STAGGER 0
+#endif
+#if CONV_STAGGER
+  // co-resident workgroups start in lockstep and then hit their prologue / epilogue phases together;
+  // a one-time skew of the first residency round spreads those phases
+  if (blockIdx.x < 768) {
+    const int slot = (blockIdx.x >> 8) % 3;
+    for (int d = 0; d < slot * CONV_STAGGER; ++d) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   int ks = 0, tile;
   bool split = false;
   if ((int)blockIdx.x < p.full_tiles) {
     tile = xcd_remap(blockIdx.x, p.full_tiles);
   } else {
     const int u = xcd_remap(blockIdx.x - p.full_tiles, gridDim.x - p.full_tiles);
-    ks = u % p.ksplit;
-    tile = p.full_tiles + u / p.ksplit;
+    const int uq = fdiv(u, p.div_ks);
+    ks = u - uq * p.ksplit;
+    tile = p.full_tiles + uq;
     split = p.ksplit > 1;
   }
-  const int tile_n = tile % p.tiles_n;
-  const int tile_m = tile / p.tiles_n;
+  const int tile_m = fdiv(tile, p.div_tn);
+  const int tile_n = tile - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int RS = p.R * p.S;
@@ -123,9 +154,9 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
     const bool rok = m < p.M;
     const int mm = rok ? m : 0;
     const int hw = p.Hout * p.Wout;
-    const int n = mm / hw;
+    const int n = fdiv(mm, p.div_hw);
     const int rem = mm - n * hw;
-    const int oh = rem / p.Wout;
+    const int oh = fdiv(rem, p.div_w);
     const int ow = rem - oh * p.Wout;
     unsigned mask = 0;
     int bh, bw;  // tap-independent part of the source coordinate
@@ -360,58 +391,86 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
 #endif
   }  // RS_T == 0
 
-  if (split) {
-    // raw partial tile; bias / add / statistics happen in splitk_epilogue_kernel
-    float* out = p.part + (size_t)ks * (p.M - p.tail_m0) * p.ldpart;
-#pragma unroll
-    for (int j = 0; j < NREP; ++j) {
-      const int col = n0 + wn * (BN / 2) + j * 32 + l31;
-#pragma unroll
-      for (int i = 0; i < MREP; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          if (m < p.M) out[(size_t)(m - p.tail_m0) * p.ldpart + col] = acc[i][j][e];
-        }
-    }
-    return;
-  }
-
-  // ---- epilogue: store, optional bias / residual add, optional fp64 channel statistics ----
-  double* red = reinterpret_cast<double*>(smem);  // [BM/64 (wm)][BN][2]
+  // ---- epilogue ----
+  // The MFMA accumulator layout gives each lane ONE column and 32 rows of its wave's 64 x 32 block: a
+  // direct store is 32 dword stores per lane and is store-issue bound (~16k cycles per tile, 30 % of a
+  // K = 256 tile).  Each wave therefore transposes block by block through its private 64 x 36-float LDS
+  // slab and stores 16-byte lanes (8 per block instead of 32); bias / residual add ride along.
+  // Statistics are taken from the accumulators (+bias) in registers, in fp64.
+  const int Nout4 = (p.Nout + 3) & ~3;
+  float* const dst = split ? p.part + (size_t)ks * (p.M - p.tail_m0) * p.ldpart : p.y;
+  const int ldd = split ? p.ldpart : p.ldy;
+  const int mrow0 = split ? p.tail_m0 : 0;           // partial slabs start at the tail's first row
+  const int colmax = split ? p.ldpart : Nout4;       // widest column a 16-byte store may touch
+  const bool wide = split || ((p.ldy & 3) == 0 && p.ldy >= Nout4 && (!p.add || (p.ldadd & 3) == 0));
+  float* wl = smem + wave * (64 * LDK);              // this wave's slab (needs >= NT/64 * 64 * LDK floats)
+  double* red = reinterpret_cast<double*>(smem);     // [BM/64 (wm)][BN][2], used after the stores
+  double st1[NREP], st2[NREP];
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
     const int lcol = wn * (BN / 2) + j * 32 + l31;
     const int col = n0 + lcol;
     const bool cok = col < p.Nout;
-    const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+    const float bv = (!split && p.bias && cok) ? p.bias[col] : 0.f;
     double s1 = 0.0, s2 = 0.0;
+    if (wide) {
 #pragma unroll
-    for (int i = 0; i < MREP; ++i) {
+      for (int i = 0; i < MREP; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-        const int m = m0 + row;
-        if (m < p.M && cok) {
-          float v = acc[i][j][e] + bv;
-          if (p.add) v += p.add[(size_t)m * p.ldadd + col];
-          p.y[(size_t)m * p.ldy + col] = v;
-          const double dv = (double)v;
-          s1 += dv;
-          s2 += dv * dv;
+        for (int e = 0; e < 16; ++e) {
+          const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          const float v = acc[i][j][e] + bv;
+          wl[lr * LDK + l31] = v;
+          if (m0 + wm * 64 + lr < p.M && cok) {
+            const double dv = (double)v;
+            s1 += dv;
+            s2 += dv * dv;
+          }
+        }
+      // same-wave LDS traffic is ordered: no barrier needed between the writes above and these reads
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int idx = lane + 64 * t;
+        const int lr = idx >> 3, c4 = (idx & 7) * 4;
+        const int m = m0 + wm * 64 + lr;
+        const int cg = n0 + wn * (BN / 2) + j * 32 + c4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&wl[lr * LDK + c4]);
+        if (m < p.M && cg < colmax) {
+          if (!split && p.add) v += *reinterpret_cast<const f32x4*>(p.add + (size_t)m * p.ldadd + cg);
+          *reinterpret_cast<f32x4*>(dst + (size_t)(m - mrow0) * ldd + cg) = v;
         }
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          if (m < p.M && cok) {
+            float v = acc[i][j][e] + bv;
+            const double dv = (double)v;
+            s1 += dv;
+            s2 += dv * dv;
+            if (p.add) v += p.add[(size_t)m * p.ldadd + col];
+            p.y[(size_t)m * p.ldy + col] = v;
+          }
+        }
     }
-    if (p.stats) {
-      s1 += shfl_xor_f64(s1, 32);
-      s2 += shfl_xor_f64(s2, 32);
+    st1[j] = s1;
+    st2[j] = s2;
+  }
+  if (!split && p.stats) {
+    __syncthreads();  // every wave is done with its transposition slab
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int lcol = wn * (BN / 2) + j * 32 + l31;
+      const double s1 = st1[j] + shfl_xor_f64(st1[j], 32);
+      const double s2 = st2[j] + shfl_xor_f64(st2[j], 32);
       if (lhi == 0) {
         red[(wm * BN + lcol) * 2 + 0] = s1;
         red[(wm * BN + lcol) * 2 + 1] = s2;
       }
     }
-  }
-  if (p.stats) {
     __syncthreads();
     if (tid < BN) {
       const int col = n0 + tid;
@@ -516,22 +575,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 // One workgroup per (co tile, ci tile, tap, K split); partial sums go to a [ksplit] slab that
 // wgrad_reduce_unpack sums deterministically while converting to the OIHW layout of .grad.
 // ------------------------------------------------------------------------------------------
-// exact n / d for 0 <= n < 2^31 by one 64-bit multiply: q = (n * mul) >> sh
-struct FastDiv {
-  unsigned mul, sh;
-};
-inline FastDiv make_fastdiv(int d) {
-  int l = 0;
-  while ((1LL << l) < d) ++l;
-  FastDiv f;
-  f.sh = 31 + l;
-  f.mul = (unsigned)(((1ULL << f.sh) + (unsigned long long)d - 1) / (unsigned long long)d);
-  return f;
-}
-__device__ __forceinline__ int fdiv(int n, FastDiv f) {
-  return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh);
-}
-
 struct WgradArgs {
   const float* x;
   const float* dy;
@@ -792,6 +835,10 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   p.ksplit = ksplit;
   p.full_tiles = ksplit > 1 ? full_tiles : tiles;
   p.part = scratch;
+  p.div_hw = make_fastdiv(a.Hout * a.Wout);
+  p.div_w = make_fastdiv(a.Wout);
+  p.div_tn = make_fastdiv(p.tiles_n);
+  p.div_ks = make_fastdiv(ksplit);
   const int grid = p.full_tiles + (tiles - p.full_tiles) * ksplit;
   // buffer-load kernels need 1x1 / 3x3 taps, split points on chunk boundaries and < 2 GB operands
 #ifndef CONV_BUFLOAD

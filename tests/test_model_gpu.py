@@ -193,3 +193,42 @@ def test_psanet50_small_vs_oracle_and_golden(report):
 ])
 def test_psanet_variants(cfg, report):
     run_case(report, "psanet50 %s" % (cfg,), "psa", 50, 19, 65, 2, psa_cfg=cfg)
+
+
+def _logits_and_losses(report, name, arch, layers, classes, size, batch, psa_cfg=None):
+    """BASELINE.json parity cases at their real spatial size: eval logits and train-mode losses of the HIP
+    model vs the fp32 oracle (the gradient statistics are covered at the smaller sizes above)."""
+    from oracle import segnet
+    kw = dict(psa_cfg) if psa_cfg else {}
+    m, sd = build(arch, layers, classes, **kw)
+    x, y = inputs(batch, size, classes)
+    with torch.no_grad():
+        ref = segnet.forward({k: v.clone() for k, v in sd.items()}, x[:1], layers, arch, training=False,
+                             psa_cfg=psa_cfg)
+        _, ml_ref, al_ref = segnet.forward({k: v.clone() for k, v in sd.items()}, x, layers, arch, training=True,
+                                           y=y, psa_cfg=psa_cfg)
+    m = m.cuda().eval()
+    out = m(x[:1].cuda())
+    e = rel(out, ref)
+    m.train()
+    pred, ml, al = m(x.cuda(), y.cuda())
+    (ml + 0.4 * al).backward()
+    torch.cuda.synchronize()
+    e_ml = abs(ml.item() - ml_ref.item()) / abs(ml_ref.item())
+    e_al = abs(al.item() - al_ref.item()) / abs(al_ref.item())
+    finite = all(torch.isfinite(p.grad).all().item() for p in m.parameters())
+    report("%s: eval logits %.2e (|ref|max %.2e) train main %.2e aux %.2e grads finite %s"
+           % (name, e, float(ref.abs().max()), e_ml, e_al, finite))
+    assert e < 1e-4 and e_ml < 1e-5 and e_al < 1e-5 and finite
+
+
+def test_config3_pspnet101_cityscapes_shape(report):
+    """BASELINE configs[2]: PSPNet101, 713x713, 19 classes (per-GPU batch 2 of the 8-GPU run)."""
+    _logits_and_losses(report, "pspnet101 c19 713^2 b2", "psp", 101, 19, 713, 2)
+
+
+def test_config4_psanet101_ade_shape(report):
+    """BASELINE configs[3]: PSANet101, 465x465, 150 classes, psa_type 2, shrink 2, full 59x59 mask."""
+    cfg = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=59, mask_w=59, normalization_factor=1.0,
+               psa_softmax=True)
+    _logits_and_losses(report, "psanet101 c150 465^2 b2 mask59", "psa", 101, 150, 465, 2, psa_cfg=cfg)
