@@ -37,15 +37,16 @@ int semseg_psamask_backward(int psa_type, const float* grad_output, float* grad_
  * ([Ci_pad][roundup32(Co)*R*S]); either destination may be NULL. */
 int semseg_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_dgrad, int Co, int Ci,
                              int R, int S, int Co_pad, int Ci_pad, hipStream_t stream);
-/* y[M][Co] = conv(x) (+bias) (+add); stats (optional, [2*Co] fp64, caller-zeroed) receives the
+/* y[M][Co] = [relu]( conv(x) (*scale) (+bias) (+add) ) — scale/bias/relu fold an eval-mode BatchNorm
+ * (+ReLU, +residual) into the epilogue; stats (optional, [2*Co] fp64, caller-zeroed) receives the
  * per-channel sum and sum of squares of y for the following BatchNorm.  tile_n in {64,128};
  * w_fwd must have Co_pad = roundup(Co, tile_n) rows.  Ci % 32 == 0.  scratch (optional) enables
  * split-K when the 128 x tile_n tile grid cannot fill the 256 CUs (small per-GPU batches). */
 int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
                     int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
-                    int dil, const float* bias, const float* add, int ldadd, double* stats,
-                    int stats_nslot, int tile_n, float* scratch, size_t scratch_floats,
-                    hipStream_t stream);
+                    int dil, const float* bias, const float* scale, int relu, const float* add,
+                    int ldadd, double* stats, int stats_nslot, int tile_n, float* scratch,
+                    size_t scratch_floats, hipStream_t stream);
 /* dx[N*H*W][Ci] = conv_transpose(dy) (+add).  dy must be readable (zero padded) up to
  * roundup32(Co) channels; w_dgrad must have roundup(Ci, tile_n) rows. */
 int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,

@@ -61,6 +61,8 @@ struct ConvArgs {
   const float* w;   // packed B^T panel [Nout_pad][KT*32]
   float* y;         // output [M][ldy]
   const float* bias;  // optional [Nout]
+  const float* scale; // optional [Nout]: y = acc*scale + bias (eval-mode BatchNorm folded in)
+  int relu;           // clamp at 0 after bias / add (eval-mode BN + ReLU (+ residual) epilogue)
   const float* add;   // optional [M][ldadd] added in the epilogue
   double* stats;      // optional [2*Nout]: per-channel sum, sum of squares (fp64 atomics)
   int ldx, ldy, ldadd;
@@ -412,6 +414,8 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
     const int col = n0 + lcol;
     const bool cok = col < p.Nout;
     const float bv = (!split && p.bias && cok) ? p.bias[col] : 0.f;
+    const float sv = (!split && p.scale && cok) ? p.scale[col] : 1.f;
+    const bool relu = !split && p.relu;
     double s1 = 0.0, s2 = 0.0;
     if (wide) {
 #pragma unroll
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          const float v = acc[i][j][e] + bv;
+          const float v = acc[i][j][e] * sv + bv;
           wl[lr * LDK + l31] = v;
           if (m0 + wm * 64 + lr < p.M && cok) {
             const double dv = (double)v;
@@ -437,6 +441,10 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
         f32x4 v = *reinterpret_cast<const f32x4*>(&wl[lr * LDK + c4]);
         if (m < p.M && cg < colmax) {
           if (!split && p.add) v += *reinterpret_cast<const f32x4*>(p.add + (size_t)m * p.ldadd + cg);
+          if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+          }
           *reinterpret_cast<f32x4*>(dst + (size_t)(m - mrow0) * ldd + cg) = v;
         }
       }
@@ -447,11 +455,12 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
         for (int e = 0; e < 16; ++e) {
           const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
           if (m < p.M && cok) {
-            float v = acc[i][j][e] + bv;
+            float v = acc[i][j][e] * sv + bv;
             const double dv = (double)v;
             s1 += dv;
             s2 += dv * dv;
             if (p.add) v += p.add[(size_t)m * p.ldadd + col];
+            if (relu) v = fmaxf(v, 0.f);
             p.y[(size_t)m * p.ldy + col] = v;
           }
         }
@@ -494,6 +503,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part,
                                                               int ksplit, int ldpart, float* y,
                                                               int ldy, const float* bias,
+                                                              const float* scale, int relu,
                                                               const float* add, int ldadd,
                                                               double* stats, int nslot, int M,
                                                               int Nout, int tpr, int rpb) {
@@ -505,10 +515,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   const int c = c4 * 4;
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (active) {
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {1.f, 1.f, 1.f, 1.f};
     if (bias) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) bv[k] = (c + k < Nout) ? bias[c + k] : 0.f;
+    }
+    if (scale) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sv[k] = (c + k < Nout) ? scale[c + k] : 1.f;
     }
     const size_t slab = (size_t)M * ldpart;
     constexpr int U = 2;
@@ -531,19 +545,23 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
       for (int u = 0; u < U; ++u) {
         const int m = mb + u * step;
         if (m < M) {
-          f32x4 r = a[u] + bv;
-          if (add) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (c + k < Nout) r[k] += add[(size_t)m * ldadd + c + k];
-          }
-          *reinterpret_cast<f32x4*>(y + (size_t)m * ldy + c) = r;
+          f32x4 r = a[u] * sv + bv;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const double d = (double)r[k];
             v[k] += d;
             v[4 + k] += d * d;
           }
+          if (add) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c + k < Nout) r[k] += add[(size_t)m * ldadd + c + k];
+          }
+          if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = fmaxf(r[k], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(y + (size_t)m * ldy + c) = r;
         }
       }
     }
@@ -878,7 +896,7 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     if (cap < 1) cap = 1;
     if (gy > cap) gy = cap;
     splitk_epilogue_kernel<<<dim3(gx, gy), 256, 0, stream>>>(
-        scratch, ksplit, p.ldpart, a.y + (size_t)p.tail_m0 * a.ldy, a.ldy, a.bias,
+        scratch, ksplit, p.ldpart, a.y + (size_t)p.tail_m0 * a.ldy, a.ldy, a.bias, a.scale, a.relu,
         a.add ? a.add + (size_t)p.tail_m0 * a.ldadd : nullptr, a.ldadd, a.stats, a.stats_nslot, Mt, a.Nout,
         tpr, rpb);
   }
@@ -887,13 +905,13 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
 
 int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
                     int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
-                    int dil, const float* bias, const float* add, int ldadd, double* stats,
-                    int stats_nslot, int tile_n, float* scratch, size_t scratch_floats,
-                    hipStream_t stream) {
+                    int dil, const float* bias, const float* scale, int relu, const float* add,
+                    int ldadd, double* stats, int stats_nslot, int tile_n, float* scratch,
+                    size_t scratch_floats, hipStream_t stream) {
   if (!x || !w_fwd || !y || Ci % 32 != 0 || (ldx & 3) || (tile_n != 64 && tile_n != 128))
     return SEMSEG_EINVAL;
   ConvArgs a;
-  a.x = x; a.w = w_fwd; a.y = y; a.bias = bias; a.add = add; a.stats = stats;
+  a.x = x; a.w = w_fwd; a.y = y; a.bias = bias; a.scale = scale; a.relu = relu; a.add = add; a.stats = stats;
   a.ldx = ldx; a.ldy = ldy; a.ldadd = ldadd;
   a.N = N; a.Hin = H; a.Win = W; a.Hout = Ho; a.Wout = Wo;
   a.Kc = Ci; a.Nout = Co; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
@@ -909,7 +927,7 @@ int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx
   const int Kc = (Co + 31) / 32 * 32;
   if (lddy < Kc) return SEMSEG_EINVAL;
   ConvArgs a;
-  a.x = dy; a.w = w_dgrad; a.y = dx; a.bias = nullptr; a.add = add; a.stats = nullptr;
+  a.x = dy; a.w = w_dgrad; a.y = dx; a.bias = nullptr; a.scale = nullptr; a.relu = 0; a.add = add; a.stats = nullptr;
   a.ldx = lddy; a.ldy = lddx; a.ldadd = ldadd;
   a.N = N; a.Hin = Ho; a.Win = Wo; a.Hout = H; a.Wout = W;
   a.Kc = Kc; a.Nout = Ci; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;

@@ -105,6 +105,7 @@ class BNL:
         self.mean, self.invstd, self.scale, self.shift = v[:C], v[C:2 * C], v[2 * C:3 * C], v[3 * C:]
         self.ggrad = None
         self.bgrad = None
+        self.eval_epoch = -1
 
 
 class Engine:
@@ -136,6 +137,7 @@ class Engine:
         self.grads_ready_hook = None  # callable(param_list) fired as parameter gradients complete
         self.weights_version = None
         self.ktimer = None
+        self._eval_epoch = 0
         self.side_wgrad = os.environ.get("SEMSEG_SIDE_WGRAD", "1") == "1"
         self._side = None
         self._scr2 = None
@@ -225,7 +227,24 @@ class Engine:
         return tuple(p._version for p in self.params) + tuple(p.data_ptr() for p in self.params[:4])
 
     # ------------------------------------------------------------------ primitive layers
-    def conv(self, x, m, stats=None, out=None, bias=False):
+    def conv_bn(self, x, m, bm, relu=True, res=None, dropmask=None, out=None):
+        """conv -> BatchNorm -> [ReLU].  Training: conv with fused statistics epilogue, then the BN apply
+        kernel.  Eval: the BatchNorm (running statistics), the ReLU and an optional residual are folded into
+        the conv epilogue (y = relu(acc*scale + shift + res)), so the raw conv output never reaches HBM."""
+        if self.training:
+            assert res is None
+            return self.bn_act(self.conv(x, m, stats=self._st(bm)), bm, relu=relu, dropmask=dropmask, out=out)
+        bl = self.bns[bm]
+        self._eval_bn(bm, bl)
+        return self.conv(x, m, out=out, fold=(bl.scale, bl.shift, relu, res))
+
+    def _eval_bn(self, bm, bl):
+        if bl.eval_epoch != self._eval_epoch:
+            ops.bn_eval_params(bm.weight.detach(), bm.bias.detach(), bm.running_mean, bm.running_var, bl.eps,
+                               bl.scale, bl.shift, bl.C)
+            bl.eval_epoch = self._eval_epoch
+
+    def conv(self, x, m, stats=None, out=None, bias=False, fold=None):
         cl = self.convs[m]
         Ho = ops.conv_out(x.H, cl.R, cl.stride, cl.pad, cl.dil)
         Wo = ops.conv_out(x.W, cl.S, cl.stride, cl.pad, cl.dil)
@@ -234,9 +253,15 @@ class Engine:
             ld = cl.Co if cl.Co % 64 == 0 else ops.roundup(cl.Co, 128)
             out = self.act(x.N, Ho, Wo, cl.Co, ld=ld, tag="conv")
         ev = self._t0("conv_igemm_kernel<128,%d,false,%d>(+splitk_epilogue)" % (cl.pk.tile_fwd, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
-        ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                     bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats,
-                     nslot=ops.NSLOT, scratch=self.scratch())
+        if fold is not None:
+            sc, sh, relu, res = fold
+            ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                         bias=sh, scale=sc, relu=relu, add=None if res is None else res.data,
+                         ldadd=0 if res is None else res.ld, scratch=self.scratch())
+        else:
+            ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                         bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats,
+                         nslot=ops.NSLOT, scratch=self.scratch())
         self._t1(ev)
         if self.training:
             self.tape.append(lambda: self._conv_bwd(x, out, cl, m))
@@ -425,8 +450,8 @@ class Engine:
                 self._ready([c0.weight])
             self.tape.append(bwd)
         a = self.bn_act(y0, l0[1])
-        a = self.bn_act(self.conv(a, l0[3], stats=self._st(l0[4])), l0[4])
-        a = self.bn_act(self.conv(a, l0[6], stats=self._st(l0[7])), l0[7])
+        a = self.conv_bn(a, l0[3], l0[4])
+        a = self.conv_bn(a, l0[6], l0[7])
         # maxpool
         Hp, Wp = ops.conv_out(a.H, 3, 2, 1, 1), ops.conv_out(a.W, 3, 2, 1, 1)
         p = self.act(N, Hp, Wp, a.C, tag="pool")
@@ -444,8 +469,11 @@ class Engine:
         return self.bns[bm].stats if (self.training and bm.training) else None
 
     def bottleneck(self, x, blk, out=None):
-        a1 = self.bn_act(self.conv(x, blk.conv1, stats=self._st(blk.bn1)), blk.bn1)
-        a2 = self.bn_act(self.conv(a1, blk.conv2, stats=self._st(blk.bn2)), blk.bn2)
+        a1 = self.conv_bn(x, blk.conv1, blk.bn1)
+        a2 = self.conv_bn(a1, blk.conv2, blk.bn2)
+        if not self.training:
+            r = x if blk.downsample is None else self.conv_bn(x, blk.downsample[0], blk.downsample[1], relu=False)
+            return self.conv_bn(a2, blk.conv3, blk.bn3, relu=True, res=r, out=out)
         y3 = self.conv(a2, blk.conv3, stats=self._st(blk.bn3))
         if blk.downsample is not None:
             yd = self.conv(x, blk.downsample[0], stats=self._st(blk.downsample[1]))
@@ -493,8 +521,7 @@ class Engine:
             pa = Act(pooled[off:off + n].view(N, b, b, C), N, b, b, C, C, "pooled%d" % b)
             off += n
             pacts.append(pa)
-            yb = self.conv(pa, f[1], stats=self._st(f[2]))
-            ab = self.bn_act(yb, f[2])
+            ab = self.conv_bn(pa, f[1], f[2])
             dst = cat.slice(c0, ab.C)
             ops.bilinear_fwd(ab.data, ab.ld, dst.data, dst.ld, N, b, b, H, W, ab.C)
             if self.training:
@@ -525,12 +552,11 @@ class Engine:
     def head(self, x, seq, tag):
         """cls / aux: conv3x3-bn-relu-dropout2d-conv1x1(+bias) (model/pspnet.py:64-78)."""
         conv_a, bn_a, drop, conv_b = seq[0], seq[1], seq[3], seq[4]
-        y = self.conv(x, conv_a, stats=self._st(bn_a))
         dm = None
         if self.training and drop.training and drop.p > 0:
-            dm = self.buf((x.N, y.C), tag="dropmask")
+            dm = self.buf((x.N, conv_a.weight.shape[0]), tag="dropmask")
             dm.bernoulli_(1.0 - drop.p).mul_(1.0 / (1.0 - drop.p))
-        a = self.bn_act(y, bn_a, dropmask=dm)
+        a = self.conv_bn(x, conv_a, bn_a, dropmask=dm)
         ncls = conv_b.weight.shape[0]
         out = self.act(x.N, x.H, x.W, ncls, ld=ops.roundup(ncls, 128), tag="scores" + tag)
         return self.conv(a, conv_b, out=out, bias=True)
@@ -562,12 +588,23 @@ class Engine:
         assert x.is_cuda and x.dtype == F32 and tuple(x.shape) == (self.N, 3, self.H, self.W)
         self._seq = 0
         self.tape = []
-        sig = self._weights_sig()
+        # parameter version counters + the model-wide counter of HIP training steps (the fused SGD
+        # kernel updates weights without touching torch's version counters)
+        sig = (self._weights_sig(), 0 if self.training else self.model.__dict__.get("_hip_bn_epoch", 0))
         if self.training or sig != self.weights_version:
             self.pack_weights()
             self.weights_version = sig
         if self.training:
             self._f64_arena.zero_()
+            self.model.__dict__["_hip_bn_epoch"] = self.model.__dict__.get("_hip_bn_epoch", 0) + 1
+        else:
+            # eval-mode scale/shift are cached until the weights, the running statistics (torch-side
+            # version counters) or a HIP training step (epoch counter on the model) change them
+            sig2 = (sig, self.model.__dict__.get("_hip_bn_epoch", 0),
+                    tuple(b._version for b in self.model.buffers()))
+            if sig2 != getattr(self, "_eval_sig", None):
+                self._eval_sig = sig2
+                self._eval_epoch += 1
         return x.contiguous()
 
     def _features(self, x):

@@ -70,12 +70,12 @@ def _scr(scratch):
 
 
 def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None, ldadd=0, stats=None,
-             nslot=1, scratch=None):
+             nslot=1, scratch=None, scale=None, relu=False):
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
     _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
-                            pk.R, pk.S, stride, pad, dil, _p(bias), _p(add), ldadd, _p(stats), nslot,
-                            pk.tile_fwd, *_scr(scratch), _stream()), "conv_fwd")
+                            pk.R, pk.S, stride, pad, dil, _p(bias), _p(scale), int(relu), _p(add), ldadd,
+                            _p(stats), nslot, pk.tile_fwd, *_scr(scratch), _stream()), "conv_fwd")
     return Ho, Wo
 
 
@@ -270,7 +270,7 @@ def gemm_rows(a_ptr, lda, bt_ptr, c_ptr, ldc, M, K, Nout, add_ptr=None, ldadd=0)
     implicit-GEMM kernel on raw device pointers."""
     tile = 128 if Nout >= 128 else 64
     _ck(lib.semseg_conv_fwd(a_ptr, lda, bt_ptr, c_ptr, ldc, 1, M, 1, K, M, 1, Nout, 1, 1, 1, 0, 1, None,
-                            add_ptr, ldadd, None, 1, tile, None, 0, _stream()), "gemm_rows")
+                            None, 0, add_ptr, ldadd, None, 1, tile, None, 0, _stream()), "gemm_rows")
 
 
 def gemm_kmajor(x_ptr, ldx, y_ptr, ldy, out_ptr, scratch, K, Ci, Co, accumulate=False):

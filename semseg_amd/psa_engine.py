@@ -27,9 +27,8 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
     N = x4.N
     sf = psa.shrink_factor
     H, W = x4.H, x4.W
-    y_red = eng.conv(x4, red[0], stats=eng._st(red[1]))
     if sf != 1:
-        xr = eng.bn_act(y_red, red[1])
+        xr = eng.conv_bn(x4, red[0], red[1])
         h, w = (H - 1) // sf + 1, (W - 1) // sf + 1
         xs = _padded_act(eng, N, h, w, xr.C, "psa_xs")
         ops.bilinear_fwd(xr.data, xr.ld, xs.data, xs.ld, N, H, W, h, w, xr.C)
@@ -41,10 +40,10 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
             eng.tape.append(bwd_shrink)
     else:
         h, w = H, W
-        xs = eng.bn_act(y_red, red[1], out=_padded_act(eng, N, h, w, y_red.C, "psa_xs"))
+        xs = eng.conv_bn(x4, red[0], red[1], out=_padded_act(eng, N, h, w, red[0].weight.shape[0], "psa_xs"))
     hw = h * w
     C = xs.C
-    a1 = eng.bn_act(eng.conv(xs, att[0], stats=eng._st(att[1])), att[1])
+    a1 = eng.conv_bn(xs, att[0], att[1])
     ym = eng.conv(a1, att[3])                       # [N,h,w,taps] (ld padded, pad = 0)
     P = ops.roundup(hw, 128)                        # affinity row stride (zero padded)
     aff = eng.buf((N * hw + PADROWS, P), zero=True, tag="psa_aff")
@@ -112,10 +111,9 @@ def psa_forward(eng, x4, cat):
         _branch(eng, x4, m.reduce_p, m.attention_p, 1, m, zcat, 512)
     else:
         _branch(eng, x4, m.reduce, m.attention, m.psa_type, m, zcat, 0)
-    yp = eng.conv(zcat, m.proj[0], stats=eng._st(m.proj[1]))
     dst = cat.slice(2048, 2048)
     if sf != 1:
-        ap = eng.bn_act(yp, m.proj[1])
+        ap = eng.conv_bn(zcat, m.proj[0], m.proj[1])
         Ho, Wo = (h - 1) * sf + 1, (w - 1) * sf + 1
         assert (Ho, Wo) == (x4.H, x4.W), "PSA expand size must match the trunk feature map"
         ops.bilinear_fwd(ap.data, ap.ld, dst.data, dst.ld, N, h, w, Ho, Wo, ap.C)
@@ -126,7 +124,7 @@ def psa_forward(eng, x4, cat):
                 ap.ginit = True
             eng.tape.append(bwd_expand)
     else:
-        eng.bn_act(yp, m.proj[1], out=dst)
+        eng.conv_bn(zcat, m.proj[0], m.proj[1], out=dst)
         if eng.training:
             def link2():
                 dst.grad = cat.grad[..., 2048:]
