@@ -681,18 +681,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     for (int i = 0; i < X_PER; ++i)
       *reinterpret_cast<f32x4*>(&Xs[(xr + i * XROWS) * TN + xc * 4]) = rx[i];
     __syncthreads();
+    // fragments of k-pair kp+1 are read from LDS while the MFMAs of k-pair kp issue (the compiler
+    // otherwise waits for every ds_read right in front of its 4 MFMAs)
+    float fa[2][MREP], fb[2][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) fa[0][i] = Ys[(lhi)*TM + wm * (TM / 2) + i * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) fb[0][j] = Xs[(lhi)*TN + wn * (TN / 2) + j * 32 + l31];
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
-      float a[MREP], bb[NREP];
+      if (kp + 1 < 16) {
 #pragma unroll
-      for (int i = 0; i < MREP; ++i) a[i] = Ys[(2 * kp + lhi) * TM + wm * (TM / 2) + i * 32 + l31];
+        for (int i = 0; i < MREP; ++i)
+          fa[(kp + 1) & 1][i] = Ys[(2 * (kp + 1) + lhi) * TM + wm * (TM / 2) + i * 32 + l31];
 #pragma unroll
-      for (int j = 0; j < NREP; ++j) bb[j] = Xs[(2 * kp + lhi) * TN + wn * (TN / 2) + j * 32 + l31];
+        for (int j = 0; j < NREP; ++j)
+          fb[(kp + 1) & 1][j] = Xs[(2 * (kp + 1) + lhi) * TN + wn * (TN / 2) + j * 32 + l31];
+      }
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][i], fb[kp & 1][j], acc[i][j], 0, 0, 0);
       if (kp == 3 && kb + 32 < kend) prefetch(kb + 32);
     }
     __syncthreads();
