@@ -37,6 +37,17 @@ int semseg_psamask_backward(int psa_type, const float* grad_output, float* grad_
  * ([Ci_pad][roundup32(Co)*R*S]); either destination may be NULL. */
 int semseg_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_dgrad, int Co, int Ci,
                              int R, int S, int Co_pad, int Ci_pad, hipStream_t stream);
+/* Every conv weight of a network in one launch.  descs_dev: device array of nconv descriptors;
+ * block_starts_dev: 2*nconv ints, the first block (1024 elements each) of conv i's forward panel
+ * ([2i]) and data-gradient panel ([2i+1]); total_blocks = one past the last block. */
+typedef struct SemsegPackDesc {
+  const float* w;   /* OIHW */
+  float* w_fwd;     /* [Co_pad][Ci*RS] */
+  float* w_dgrad;   /* [Ci_pad][Kc_dgrad*RS] */
+  int Co, Ci, RS, Co_pad, Ci_pad, Kc_dgrad;
+} SemsegPackDesc;
+int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* block_starts_dev,
+                                   int nconv, int total_blocks, hipStream_t stream);
 /* y[M][Co] = [relu]( conv(x) (*scale) (+bias) (+add) ) — scale/bias/relu fold an eval-mode BatchNorm
  * (+ReLU, +residual) into the epilogue; stats (optional, [2*Co] fp64, caller-zeroed) receives the
  * per-channel sum and sum of squares of y for the following BatchNorm.  tile_n in {64,128};

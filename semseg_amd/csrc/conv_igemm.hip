@@ -11,6 +11,7 @@
 //
 // Tile: 256 threads = 4 waves (2x2), block tile BM x BN x 32, each wave (BM/2)x(BN/2) as
 // 32x32 MFMA blocks; global->register prefetch of K-step t+1 overlaps the MFMAs of step t.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -781,6 +782,42 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict
   }
 }
 
+// All conv weights of a network in ONE launch: block b finds its (conv, panel) by binary search over
+// the block-start table; 1024 elements per block.
+__global__ __launch_bounds__(256) void pack_multi_kernel(const SemsegPackDesc* __restrict__ descs,
+                                                         const int* __restrict__ starts, int nseg) {
+  // starts[2*i] = first block of conv i's forward panel, starts[2*i+1] = first block of its dgrad panel
+  int lo = 0, hi = nseg - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const SemsegPackDesc d = descs[lo >> 1];
+  const bool dgrad = lo & 1;
+  const size_t base = (size_t)(b - starts[lo]) * 1024;
+  const int RS = d.RS;
+  const int Kc = dgrad ? d.Kc_dgrad : d.Ci;
+  const size_t total = (size_t)(dgrad ? d.Ci_pad : d.Co_pad) * Kc * RS;
+  float* out = dgrad ? d.w_dgrad : d.w_fwd;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const size_t idx = base + t * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int c32 = (int)(idx % 32);
+    size_t q = idx / 32;
+    const int tap = (int)(q % RS);
+    q /= RS;
+    const int chunk = (int)(q % (Kc / 32));
+    const int row = (int)(q / (Kc / 32));
+    const int k = chunk * 32 + c32;
+    const int co = dgrad ? k : row, ci = dgrad ? row : k;
+    float v = 0.f;
+    if (co < d.Co && ci < d.Ci) v = d.w[((size_t)co * d.Ci + ci) * RS + tap];
+    out[idx] = v;
+  }
+}
+
 inline int grid_for(size_t total, int block) {
   size_t g = (total + block - 1) / block;
   if (g > 8192) g = 8192;
@@ -813,6 +850,13 @@ int semseg_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_dgrad, 
 #ifndef CONV_BM256
 #define CONV_BM256 0
 #endif
+int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* block_starts_dev,
+                                   int nconv, int total_blocks, hipStream_t stream) {
+  if (!descs_dev || !block_starts_dev || nconv < 1 || total_blocks < 1) return SEMSEG_EINVAL;
+  pack_multi_kernel<<<total_blocks, 256, 0, stream>>>(descs_dev, block_starts_dev, 2 * nconv);
+  return semseg_launch_status();
+}
+
 static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratch,
                        size_t scratch_floats, hipStream_t stream) {
   // 256-row tiles (8 waves) halve the weight-panel traffic per MFMA; used when the grid is large
@@ -832,7 +876,8 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   p.ldpart = p.tiles_n * BN;
   const bool can_split = scratch && (a.ldy & 3) == 0 && a.ldy >= ((a.Nout + 3) & ~3) && KT >= 8;
   if (can_split && tiles < 384) {
-    ksplit = (640 + tiles - 1) / tiles;
+    static const int target = getenv("SEMSEG_SPLITK_TARGET") ? atoi(getenv("SEMSEG_SPLITK_TARGET")) : 448;
+    ksplit = (target + tiles - 1) / tiles;
     if (ksplit > KT / 4) ksplit = KT / 4;
     if (ksplit > 16) ksplit = 16;
     full_tiles = 0;

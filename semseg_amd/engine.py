@@ -219,9 +219,34 @@ class Engine:
 
     # ------------------------------------------------------------------ weights
     def pack_weights(self):
-        for m, cl in self.convs.items():
-            if cl is not None:
-                cl.pk.pack(m.weight.detach())
+        """One launch packs every conv weight (forward + data-gradient panels)."""
+        import ctypes
+        import numpy as np
+        items = [(m, cl) for m, cl in self.convs.items() if cl is not None]
+        ptrs = tuple(m.weight.data_ptr() for m, _ in items)
+        if getattr(self, "_pack_ptrs", None) != ptrs:
+            class Desc(ctypes.Structure):
+                _fields_ = [("w", ctypes.c_void_p), ("w_fwd", ctypes.c_void_p), ("w_dgrad", ctypes.c_void_p),
+                            ("Co", ctypes.c_int), ("Ci", ctypes.c_int), ("RS", ctypes.c_int),
+                            ("Co_pad", ctypes.c_int), ("Ci_pad", ctypes.c_int), ("Kc_dgrad", ctypes.c_int)]
+            arr = (Desc * len(items))()
+            starts, blk = [], 0
+            for i, (m, cl) in enumerate(items):
+                pk = cl.pk
+                RS = pk.R * pk.S
+                arr[i] = Desc(m.weight.data_ptr(), pk.w_fwd.data_ptr(), pk.w_dgrad.data_ptr(), pk.Co, pk.Ci, RS,
+                              pk.Co_pad, pk.Ci_pad, pk.Kc_dgrad)
+                starts.append(blk)
+                blk += (pk.Co_pad * pk.Ci * RS + 1023) // 1024
+                starts.append(blk)
+                blk += (pk.Ci_pad * pk.Kc_dgrad * RS + 1023) // 1024
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            self._pack_descs = torch.from_numpy(raw).to(self.device)
+            self._pack_starts = torch.tensor(starts, dtype=torch.int32, device=self.device)
+            self._pack_blocks = blk
+            self._pack_n = len(items)
+            self._pack_ptrs = ptrs
+        ops.conv_pack_weights_multi(self._pack_descs, self._pack_starts, self._pack_n, self._pack_blocks)
 
     def _weights_sig(self):
         return tuple(p._version for p in self.params) + tuple(p.data_ptr() for p in self.params[:4])

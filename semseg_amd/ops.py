@@ -69,6 +69,11 @@ def _scr(scratch):
     return (None, 0) if scratch is None else (scratch.data_ptr(), scratch.numel())
 
 
+def conv_pack_weights_multi(descs_dev, starts_dev, nconv, total_blocks):
+    _ck(lib.semseg_conv_pack_weights_multi(_p(descs_dev), _p(starts_dev), nconv, total_blocks, _stream()),
+        "conv_pack_weights_multi")
+
+
 def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None, ldadd=0, stats=None,
              nslot=1, scratch=None, scale=None, relu=False):
     Ho = conv_out(H, pk.R, stride, pad, dil)
