@@ -1,0 +1,43 @@
+"""Digest gpurun_out/r01_{stats,fetch,write,mfma} (rocprofv3 CSVs of bench.py) into profiles/."""
+import csv, collections, json, re, shutil, sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+def short(n):
+    n = n.replace('(anonymous namespace)::', '')
+    m = re.match(r'(void )?([\w:<>, ]+?)\(', n)
+    return (m.group(2) if m else n).strip()
+def agg(path):
+    a = collections.defaultdict(lambda: collections.defaultdict(float)); seen = collections.defaultdict(dict)
+    for r in csv.DictReader(open(path)):
+        k = short(r['Kernel_Name'])
+        a[k][r['Counter_Name']] += float(r['Counter_Value'])
+        seen[k][r['Dispatch_Id']] = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+    return {k: dict(c, launches=len(seen[k]), dur_ns=sum(seen[k].values())) for k, c in a.items()}
+g = os.path.join(ROOT, "gpurun_out")
+f = agg(os.path.join(g, tag + "_fetch", "pmc_counter_collection.csv"))
+w = agg(os.path.join(g, tag + "_write", "pmc_counter_collection.csv"))
+m = agg(os.path.join(g, tag + "_mfma", "pmc_counter_collection.csv"))
+res = {}
+for k in f:
+    if not any(t in k for t in ("conv_igemm", "conv_wgrad", "bn_", "splitk")): continue
+    n = f[k]['launches']
+    fetch = f[k]['FETCH_SIZE'] * 1024 * 2 / n
+    write = w.get(k, {}).get('WRITE_SIZE', 0) * 1024 / max(w.get(k, {}).get('launches', 1), 1)
+    mm = m.get(k, {}); util = clk = None
+    if mm.get('GRBM_GUI_ACTIVE'):
+        util = mm.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (mm['GRBM_GUI_ACTIVE'] / 8 * 1024)
+        clk = mm['GRBM_GUI_ACTIVE'] / 8 / mm['dur_ns']
+    res[k] = {"launches_per_2_steps": n, "hbm_fetch_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
+              "hbm_bytes_per_launch": round(fetch + write), "mfma_busy_frac": None if util is None else round(util, 4),
+              "clock_ghz": None if clk is None else round(clk, 3)}
+json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE> (three separate passes) --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing",
+           "corrections": "FETCH_SIZE and WRITE_SIZE are KB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs)",
+           "kernels": res}, open(os.path.join(ROOT, "profiles", tag + "_pmc_per_kernel.json"), "w"), indent=1)
+shutil.copy(os.path.join(g, tag + "_stats", "bench_kernel_stats.csv"), os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv"))
+shutil.copy(os.path.join(g, "bench_%s_n1.json" % tag), os.path.join(ROOT, "profiles", tag + "_bench_n1.json"))
+for k, v in sorted(res.items(), key=lambda kv: -(kv[1]['mfma_busy_frac'] or 0))[:8]: print(k, v['mfma_busy_frac'], v['hbm_bytes_per_launch'])
+d = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_n1.json")))
+print(d['value'], d['ms_per_step'], d['whole_step_frac_of_f32_mfma_peak']); print(d['roofline'])
+for k, v in d['kernel_families'].items(): print(' ', k, v)
+rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv"))))
+for r in rows[:6]: print(short(r['Name']), r['Calls'], "avg us %.1f" % (float(r['AverageNs']) / 1e3))
