@@ -529,3 +529,29 @@ def test_intersection_and_union(report):
     assert np.array_equal(u.cpu().numpy(), (ao + at - ai).astype(np.float32))
     assert np.array_equal(tt.cpu().numpy(), at.astype(np.float32))
     report("intersectionAndUnionGPU == numpy reference (exact)")
+
+
+@pytest.mark.parametrize("Ci,k,rows_n", [(2048, 1, 2), (512, 3, 2), (4096, 3, 2)])
+def test_conv_rounding_noise_vs_reduction_length(Ci, k, rows_n, report):
+    """fp32 MFMA accumulates sequentially along K = Ci*R*S inside one split, so rounding noise grows ~sqrt(K):
+    measured rms 2.3e-6 at K=36864 unsplit (7x torch CPU's blocked summation), 5.7e-7 with split-K (1.8x).
+    Bounds: split-K rms <= 3x the CPU fp32 rms (+1e-7); unsplit rms <= 1e-5.  See DESIGN.md section 9.1."""
+    from semseg_amd import ops
+    Co, N, H = 512, rows_n, 8
+    g = torch.Generator().manual_seed(Ci + k)
+    x = torch.relu(torch.randn(N, Ci, H, H, generator=g))
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), None, 1, k // 2)
+    rms = lambda a: float(((a - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+    e_cpu = rms(F.conv2d(x, w, None, 1, k // 2).double())
+    pk = ops.PackedConv(Co, Ci, k, k, DEV)
+    pk.pack(w.to(DEV))
+    xd = nhwc(x).contiguous().to(DEV)
+    errs = []
+    for scratch in (None, torch.empty(64 * 1024 * 1024, device=DEV)):
+        yb = torch.empty(N, H, H, Co, device=DEV)
+        ops.conv_fwd(xd, Ci, pk, yb, Co, N, H, H, 1, k // 2, 1, scratch=scratch)
+        torch.cuda.synchronize()
+        errs.append(rms(nchw(yb).cpu().double()))
+    report("conv noise K=%d: rms unsplit %.2e split-K %.2e torch-cpu-fp32 %.2e" % (Ci * k * k, errs[0], errs[1], e_cpu))
+    assert errs[1] <= 3.0 * e_cpu + 1e-7 and errs[0] <= 1e-5
