@@ -23,8 +23,11 @@ constexpr int BK = 32;   // K-step (floats)
 constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 conflict-free
 
 // tuning knobs (scripts/tune_conv.py builds variants with -D...)
+#ifndef CONV_TWO_LEVEL
+#define CONV_TWO_LEVEL 1
+#endif
 #ifndef CONV_OCC
-#define CONV_OCC 1
+#define CONV_OCC 2
 #endif
 #ifndef CONV_DBUF
 #define CONV_DBUF 0
@@ -88,7 +91,7 @@ struct ConvArgs {
 // and the gather uses buffer loads with per-(row,tap) byte offsets precomputed in VGPRs (invalid taps
 // carry an out-of-range offset, which the buffer unit returns as 0) plus one scalar offset per K-step —
 // no per-K-step address VALU between the MFMAs at all.
-template <int BM, int BN, bool TR, int RS_T>
+template <int BM, int BN, bool TR, int RS_T, bool TL>
 __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const ConvArgs p) {
   // BM/64 x 2 waves, each a 64 x (BN/2) sub-tile of 32x32 MFMA blocks
   constexpr int NT = BM * 2;                 // threads
@@ -233,6 +236,33 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
     for (int j = 0; j < NREP; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // Two-level accumulation: the MFMA chain sums sequentially along K, so its rounding noise grows ~sqrt(K)
+  // (rms 2.3e-6 at K = 36864, 7x a blocked CPU sum).  Every ~1024 K the chain is flushed into a second
+  // accumulator set, which bounds the chain length.  TL is set by the launcher for K >= 4096 on the
+  // BN = 128 tiles only (240 VGPRs, still occupancy 2); shorter reductions keep the leaner kernel.
+  constexpr bool TWO_LEVEL = CONV_TWO_LEVEL && TL;
+  f32x16 acc2[TWO_LEVEL ? MREP : 1][TWO_LEVEL ? NREP : 1];
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+  }
+  auto flush = [&] {
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            acc2[i][j][e] += acc[i][j][e];
+            acc[i][j][e] = 0.f;
+          }
+    }
+  };
 
   auto stage_store = [&](float* A_, float* B_) {
 #pragma unroll
@@ -358,6 +388,8 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
         step(std::integral_constant<int, 7>{}, c);
         step(std::integral_constant<int, 8>{}, c);
       }
+      // every 4 channel blocks x 9 taps (1152 K) / every 32 channel blocks (1024 K)
+      if (((c - c_begin) & (RS_T == 9 ? 3 : 31)) == (RS_T == 9 ? 3 : 31)) flush();
     }
   } else {
   prefetch(kt0);
@@ -390,9 +422,18 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
     __syncthreads();
     compute(As, Bs, [&] { if (kt + 1 < KT) prefetch(kt + 1); });
     __syncthreads();
+    if (((kt - kt0) & 31) == 31) flush();
   }
 #endif
   }  // RS_T == 0
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
+  }
 
   // ---- epilogue ----
   // The MFMA accumulator layout gives each lane ONE column and 32 rows of its wave's 64 x 32 block: a
@@ -921,7 +962,13 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   const size_t x_bytes = (size_t)a.N * a.Hin * a.Win * a.ldx * 4, w_bytes = (size_t)p.tiles_n * BN * KT * BK * 4;
   const bool bl = CONV_BUFLOAD && !big && (RSv == 1 || RSv == 9) && (p.kt_per % RSv == 0) &&
                   x_bytes < 0x7FFF0000ull && w_bytes < 0x7FFF0000ull;
-#define LAUNCH_CONV(BM_, BN_, TR_, RS_) conv_igemm_kernel<BM_, BN_, TR_, RS_><<<grid, BM_ * 2, 0, stream>>>(p)
+  const bool tl = BN == 128 && KT >= 128;      // two-level accumulation for K >= 4096 (see the kernel)
+#define LAUNCH_CONV_(BM_, BN_, TR_, RS_, TL_) conv_igemm_kernel<BM_, BN_, TR_, RS_, TL_><<<grid, BM_ * 2, 0, stream>>>(p)
+#define LAUNCH_CONV(BM_, BN_, TR_, RS_)                                        \
+  do {                                                                         \
+    if (BN_ == 128 && tl) LAUNCH_CONV_(BM_, BN_, TR_, RS_, (BN_ == 128));      \
+    else LAUNCH_CONV_(BM_, BN_, TR_, RS_, false);                              \
+  } while (0)
 #define LAUNCH_RS(BM_, BN_, TR_)                                   \
   do {                                                             \
     if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);             \
@@ -940,6 +987,7 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   }
 #undef LAUNCH_RS
 #undef LAUNCH_CONV
+#undef LAUNCH_CONV_
   if (ksplit > 1) {
     const int Mt = a.M - p.tail_m0;  // rows covered by split tiles
     const int CV = (a.Nout + 3) / 4;

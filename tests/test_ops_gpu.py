@@ -533,9 +533,11 @@ def test_intersection_and_union(report):
 
 @pytest.mark.parametrize("Ci,k,rows_n", [(2048, 1, 2), (512, 3, 2), (4096, 3, 2)])
 def test_conv_rounding_noise_vs_reduction_length(Ci, k, rows_n, report):
-    """fp32 MFMA accumulates sequentially along K = Ci*R*S inside one split, so rounding noise grows ~sqrt(K):
-    measured rms 2.3e-6 at K=36864 unsplit (7x torch CPU's blocked summation), 5.7e-7 with split-K (1.8x).
-    Bounds: split-K rms <= 3x the CPU fp32 rms (+1e-7); unsplit rms <= 1e-5.  See DESIGN.md section 9.1."""
+    """fp32 MFMA accumulates sequentially along K = Ci*R*S, so rounding noise grows ~sqrt(K) with the chain
+    length: a single chain measured rms 2.3e-6 at K=36864 (7x torch CPU's blocked summation).  The kernel
+    therefore flushes into a second accumulator set every ~1024 K when K >= 4096 (4.1e-7 at K=36864, 1.3x CPU);
+    K=2048 unsplit stays a single chain (5.8e-7, 2.7x CPU).  Regression guard, bounds set from those
+    measurements: split-K rms <= 3x CPU fp32 rms (+1e-7), unsplit <= 4x (+1e-7).  DESIGN.md section 2.1."""
     from semseg_amd import ops
     Co, N, H = 512, rows_n, 8
     g = torch.Generator().manual_seed(Ci + k)
@@ -554,4 +556,4 @@ def test_conv_rounding_noise_vs_reduction_length(Ci, k, rows_n, report):
         torch.cuda.synchronize()
         errs.append(rms(nchw(yb).cpu().double()))
     report("conv noise K=%d: rms unsplit %.2e split-K %.2e torch-cpu-fp32 %.2e" % (Ci * k * k, errs[0], errs[1], e_cpu))
-    assert errs[1] <= 3.0 * e_cpu + 1e-7 and errs[0] <= 1e-5
+    assert errs[1] <= 3.0 * e_cpu + 1e-7 and errs[0] <= 4.0 * e_cpu + 1e-7
