@@ -65,7 +65,9 @@ int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx
                       int pad, int dil, const float* add, int ldadd, int tile_n, float* scratch,
                       size_t scratch_floats, hipStream_t stream);
 /* dw_oihw[Co][Ci][R][S] (=|+=) sum over pixels; scratch holds the split-K partial slabs
- * (>= semseg_conv_wgrad_scratch_floats(...) floats; more slabs => more K parallelism).
+ * (>= semseg_conv_wgrad_scratch_floats(...) floats; more slabs => more K parallelism AND shorter fp32
+ * accumulation chains: with a single slab the whole pixel reduction is one chain and its rounding noise
+ * is 3-10x a blocked CPU sum at M >= 57600 rows; with 64 Mi floats, as the engine passes, it is 0.9-1.3x).
  * dy must be readable (zero padded) up to roundup(Co, 64 or 128) channels.  Ci % 64 == 0. */
 int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
                       float* scratch, size_t scratch_floats, int N, int H, int W, int Ci, int Ho,
