@@ -54,3 +54,54 @@ def test_cpu_model_refuses_to_run():
     m = PSPNet(layers=50, classes=5, pretrained=False).eval()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 9, 9))
+
+
+def test_pretrained_trunk_file_is_loaded(tmp_path, monkeypatch):
+    """`pretrained=True` reads ./initmodel/resnet{L}_v2.pth (reference model/resnet.py:196-200: published
+    ImageNet file, keys conv1/bn1/.../layerK.B.*/fc.*, loaded with strict=False) and the weights appear under
+    the segmentation model's own keys (layer0.N.*, layerK.*) — model/pspnet.py:37-43."""
+    import sys
+    import torch
+    from model.pspnet import PSPNet
+    from model import resnet as own
+    keys_from = None
+    if os.path.isdir("/root/reference/model"):      # key set of the reference's own ResNet when it is present
+        sys.path.insert(0, "/root/reference")
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("ref_resnet", "/root/reference/model/resnet.py")
+            ref = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(ref)
+            keys_from = ref.resnet50(pretrained=False).state_dict()
+        finally:
+            sys.path.remove("/root/reference")
+    if keys_from is None:
+        keys_from = dict(own.build_trunk(50, False).state_dict())
+        keys_from["fc.weight"] = torch.zeros(1000, 2048)
+        keys_from["fc.bias"] = torch.zeros(1000)
+    g = torch.Generator().manual_seed(5)
+    published = {k: (torch.randn(v.shape, generator=g) if v.is_floating_point() else v.clone())
+                 for k, v in keys_from.items()}
+    assert "fc.weight" in published and "conv1.weight" in published and "layer4.2.conv3.weight" in published
+    (tmp_path / "initmodel").mkdir()
+    torch.save(published, str(tmp_path / "initmodel" / "resnet50_v2.pth"))
+    monkeypatch.chdir(tmp_path)
+    m = PSPNet(layers=50, classes=5, pretrained=True)
+    sd = m.state_dict()
+    stem = {"conv1": "layer0.0", "bn1": "layer0.1", "conv2": "layer0.3", "bn2": "layer0.4", "conv3": "layer0.6",
+            "bn3": "layer0.7"}
+    checked = 0
+    for k, v in published.items():
+        if k.startswith("fc."):
+            continue
+        head, _, rest = k.partition(".")
+        mk = (stem[head] + "." + rest) if head in stem else k
+        assert mk in sd, (k, mk)
+        assert torch.equal(sd[mk], v), mk
+        checked += 1
+    assert checked == len(published) - 2
+    # without the file the constructor fails like the reference does
+    monkeypatch.chdir(tmp_path / "initmodel")
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        PSPNet(layers=50, classes=5, pretrained=True)
