@@ -191,8 +191,9 @@ def main():
         ips = args.global_batch * args.steps / dt
         step_flops = (3.0 * fwd_flops - first_flops) * args.global_batch
         out = {
-            "metric": "images/sec (train step) PSPNet-%d %dx%d bs=%d" % (args.layers, args.size, args.size,
-                                                                     args.global_batch),
+            "metric": "images/sec (train step) %s-%d %dx%d bs=%d" % ("PSPNet" if args.arch == "psp" else "PSANet",
+                                                                 args.layers, args.size, args.size,
+                                                                 args.global_batch),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
