@@ -4,12 +4,11 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "semseg_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_variants")
-VARIANTS = {
-    "old_a": ["-DCONV_TWO_LEVEL=0", "-DCONV_OCC=1"],
-    "new_a": [],
-    "old_b": ["-DCONV_TWO_LEVEL=0", "-DCONV_OCC=1"],
-    "new_b": [],
-    "occ2_only": ["-DCONV_TWO_LEVEL=0", "-DCONV_OCC=2"],
+VARIANTS = {   # last used set; earlier sets are listed in DESIGN.md section 8.1
+    "base_a": [],
+    "abl1_noglobal": ["-DWGRAD_ABL=1"],
+    "abl2_nolds_store": ["-DWGRAD_ABL=2"],
+    "base_b": [],
 }
 SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "infer.hip", "optim.hip"]
 if sys.argv[1] == "build":
@@ -25,5 +24,5 @@ else:
     for tag in VARIANTS:
         env = dict(os.environ, SEMSEG_HIP_LIB=os.path.join(OUT, "lib_%s.so" % tag))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "conv_bench.py")], env=env, capture_output=True, text=True)
-        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("l2 conv2", "l3 conv1", "l3 conv2", "l3 conv3", "l4 conv", "cls.0", "aux.0", "weighted"))]
+        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("l1 conv3", "l3 conv1", "l3 conv2", "l3 conv3", "l4 conv", "cls.0", "weighted"))]
         print("==", tag); print("\n".join(lines)); sys.stdout.flush()

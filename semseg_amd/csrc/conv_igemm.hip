@@ -23,6 +23,15 @@ constexpr int BK = 32;   // K-step (floats)
 constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 conflict-free
 
 // tuning knobs (scripts/tune_conv.py builds variants with -D...)
+#ifndef WGRAD_ABL
+#define WGRAD_ABL 0
+#endif
+#ifndef WGRAD_XCD
+#define WGRAD_XCD 1
+#endif
+#ifndef WGRAD_PF_KP
+#define WGRAD_PF_KP 3
+#endif
 #ifndef CONV_TWO_LEVEL
 #define CONV_TWO_LEVEL 1
 #endif
@@ -649,7 +658,10 @@ struct WgradArgs {
   FastDiv div_hw, div_wo;
 };
 
-template <int TM, int TN>
+// MODE 0: generic gather (any stride / padding).  MODE 1: 1x1, stride 1, pad 0 — the gathered row IS row m,
+// no decode, always valid.  MODE 2: stride 1 with Ho x Wo == Hin x Win ("same" 3x3, any dilation) — the
+// gathered row is m + tap offset (linear); the pixel is decoded only for the border test.
+template <int TM, int TN, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   constexpr int MREP = TM / 64, NREP = TN / 64;
   constexpr int YV = TM / 4, XV = TN / 4;          // float4 per k-row
@@ -665,7 +677,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int RS = p.R * p.S;
+  // XCD-aware order: workgroups that share a pixel range (same ks) and neighbouring taps / tiles read the
+  // same x and dy rows; give each XCD a contiguous chunk of the logical order so those rows are fetched
+  // into one L2 instead of all eight.
+#if WGRAD_XCD
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+#else
   int b = blockIdx.x;
+#endif
   const int tci = b % p.tiles_ci; b /= p.tiles_ci;
   const int tco = b % p.tiles_co; b /= p.tiles_co;
   const int tap = b % RS;
@@ -681,8 +700,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 
   f32x4 ry[Y_PER], rx[X_PER];
   const int tapoff = ((r * p.dil - p.pad) * p.Win + (s * p.dil - p.pad)) * p.ldx + ci0 + xc * 4;
-  // (buffer loads were measured neutral-to-negative here: the pixel decode VALU remains either way)
-  auto prefetch = [&](int kb) {
+  // linear modes: row m of the gather is x + (m + tap offset) * ldx (the offset may be negative)
+  const float* const xlin = p.x + (ptrdiff_t)tapoff;
+  // Measured on this kernel (scripts/tune_conv.py): without the in-loop global loads it
+  // runs 13 % faster (WGRAD_ABL=1), yet none of these moved it: buffer loads (neutral/negative), dropping the
+  // decode entirely for 1x1 (MODE 1, +2 %), issuing the prefetch at kp 0 instead of 3 (neutral), a two-step
+  // deep register prefetch (occupancy 3 -> 2, -5.6 %), XCD-aware block order (neutral in time), K-contiguous
+  // LDS with ds_read_b128 fragments (-1 %).
+  auto prefetch_into = [&](int kb, f32x4 (&ry)[Y_PER], f32x4 (&rx)[X_PER]) {
 #pragma unroll
     for (int i = 0; i < Y_PER; ++i) {
       const int m = kb + yr + i * YROWS;
@@ -692,19 +717,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < X_PER; ++i) {
       const int m = kb + xr + i * XROWS;
-      const int mm = m < kend ? m : kbeg;
-      const int n = fdiv(mm, p.div_hw);
-      const int rem = mm - n * hw;
-      const int oh = fdiv(rem, p.div_wo);
-      const int ow = rem - oh * p.Wo;
-      const int ih = oh * p.stride + r * p.dil - p.pad;
-      const int iw = ow * p.stride + s * p.dil - p.pad;
-      const bool ok = m < kend && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
-      const float* src =
-          ok ? p.x + (((n * p.Hin + oh * p.stride) * p.Win + ow * p.stride) * p.ldx + tapoff) : g_zero_line;
-      rx[i] = *reinterpret_cast<const f32x4*>(src);
+      if constexpr (MODE == 1) {
+        const float* src = m < kend ? xlin + (size_t)m * p.ldx : g_zero_line;
+        rx[i] = *reinterpret_cast<const f32x4*>(src);
+      } else {
+        const int mm = m < kend ? m : kbeg;
+        const int n = fdiv(mm, p.div_hw);
+        const int rem = mm - n * hw;
+        const int oh = fdiv(rem, p.div_wo);
+        const int ow = rem - oh * p.Wo;
+        const int ih = oh * p.stride + r * p.dil - p.pad;
+        const int iw = ow * p.stride + s * p.dil - p.pad;
+        const bool ok = m < kend && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        const float* src;
+        if constexpr (MODE == 2)
+          src = ok ? xlin + (size_t)m * p.ldx : g_zero_line;
+        else
+          src = ok ? p.x + (((n * p.Hin + oh * p.stride) * p.Win + ow * p.stride) * p.ldx + tapoff)
+                   : g_zero_line;
+        rx[i] = *reinterpret_cast<const f32x4*>(src);
+      }
     }
   };
+  auto prefetch = [&](int kb) { prefetch_into(kb, ry, rx); };
 
   f32x16 acc[MREP][NREP];
 #pragma unroll
@@ -714,8 +749,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // WGRAD_ABL (measurement only, results are wrong): 1 = no global loads in the loop, 2 = additionally no
+  // LDS stores / barriers per step, 3 = additionally fragments from registers (pure MFMA ceiling)
   if (kbeg < kend) prefetch(kbeg);
+#if WGRAD_ABL >= 2
+#pragma unroll
+  for (int i = 0; i < Y_PER; ++i)
+    *reinterpret_cast<f32x4*>(&Ys[(yr + i * YROWS) * TM + yc * 4]) = ry[i];
+#pragma unroll
+  for (int i = 0; i < X_PER; ++i)
+    *reinterpret_cast<f32x4*>(&Xs[(xr + i * XROWS) * TN + xc * 4]) = rx[i];
+  __syncthreads();
+#endif
   for (int kb = kbeg; kb < kend; kb += 32) {
+#if WGRAD_ABL < 2
 #pragma unroll
     for (int i = 0; i < Y_PER; ++i)
       *reinterpret_cast<f32x4*>(&Ys[(yr + i * YROWS) * TM + yc * 4]) = ry[i];
@@ -723,6 +770,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     for (int i = 0; i < X_PER; ++i)
       *reinterpret_cast<f32x4*>(&Xs[(xr + i * XROWS) * TN + xc * 4]) = rx[i];
     __syncthreads();
+#endif
     // fragments of k-pair kp+1 are read from LDS while the MFMAs of k-pair kp issue (the compiler
     // otherwise waits for every ds_read right in front of its 4 MFMAs)
     float fa[2][MREP], fb[2][NREP];
@@ -733,21 +781,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
       if (kp + 1 < 16) {
+#if WGRAD_ABL >= 3
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) { fa[(kp + 1) & 1][i] = fa[kp & 1][i]; asm volatile("" : "+v"(fa[(kp + 1) & 1][i])); }
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) { fb[(kp + 1) & 1][j] = fb[kp & 1][j]; asm volatile("" : "+v"(fb[(kp + 1) & 1][j])); }
+#else
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
           fa[(kp + 1) & 1][i] = Ys[(2 * (kp + 1) + lhi) * TM + wm * (TM / 2) + i * 32 + l31];
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
           fb[(kp + 1) & 1][j] = Xs[(2 * (kp + 1) + lhi) * TN + wn * (TN / 2) + j * 32 + l31];
+#endif
       }
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][i], fb[kp & 1][j], acc[i][j], 0, 0, 0);
-      if (kp == 3 && kb + 32 < kend) prefetch(kb + 32);
+#if WGRAD_ABL == 0
+      if (kp == WGRAD_PF_KP && kb + 32 < kend) prefetch(kb + 32);
+#endif
     }
+#if WGRAD_ABL < 2
     __syncthreads();
+#endif
   }
 
   float* out = p.dw + (size_t)ks * p.Co_pad * RS * p.Ci;
@@ -1061,16 +1120,17 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
   a.div_wo = make_fastdiv(Wo);
   const int tiles = a.tiles_co * a.tiles_ci * RS;
   const int ksteps = (M + 31) / 32;
-  // aim at one full residency round (256 CUs x 3 workgroups) without spilling into a second one
-  int ksplit = 768 / tiles;
-  if (tiles > 384) {
+  // aim at one full residency round (256 CUs x resident workgroups per CU) without spilling into a second
+  constexpr int ROUND = 768;
+  int ksplit = ROUND / tiles;
+  if (tiles > ROUND / 2) {
     // more than half a round of tiles already: pick the K split whose workgroup count fills whole
     // residency rounds best (e.g. cls.0: 1152 tiles -> x2 = 2304 = 3 rounds exactly)
     double best = 0.0;
     ksplit = 1;
     for (int ks = 1; ks <= 8; ++ks) {
       const int wgs = tiles * ks;
-      const double eff = (double)wgs / (double)(((wgs + 767) / 768) * 768);
+      const double eff = (double)wgs / (double)(((wgs + ROUND - 1) / ROUND) * ROUND);
       if (eff > best + 0.02) { best = eff; ksplit = ks; }
     }
   }
@@ -1083,10 +1143,19 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
   ksplit = (M + a.kper - 1) / a.kper;
   a.ksplit = ksplit;
   const int grid = tiles * ksplit;
-  if (big)
-    conv_wgrad_kernel<128, 128><<<grid, 256, 0, stream>>>(a);
-  else
-    conv_wgrad_kernel<64, 64><<<grid, 256, 0, stream>>>(a);
+#ifndef CONV_WGRAD_LINEAR
+#define CONV_WGRAD_LINEAR 1
+#endif
+  const bool same = CONV_WGRAD_LINEAR && stride == 1 && Ho == H && Wo == W;
+  const int mode = !same ? 0 : (RS == 1 && pad == 0) ? 1 : 2;
+#define LAUNCH_WGRAD(TM_, TN_)                                                        \
+  do {                                                                                \
+    if (mode == 1) conv_wgrad_kernel<TM_, TN_, 1><<<grid, 256, 0, stream>>>(a);       \
+    else if (mode == 2) conv_wgrad_kernel<TM_, TN_, 2><<<grid, 256, 0, stream>>>(a);  \
+    else conv_wgrad_kernel<TM_, TN_, 0><<<grid, 256, 0, stream>>>(a);                 \
+  } while (0)
+  if (big) LAUNCH_WGRAD(128, 128); else LAUNCH_WGRAD(64, 64);
+#undef LAUNCH_WGRAD
   const size_t total = (size_t)Co * Ci * RS;
   wgrad_reduce_unpack_kernel<<<grid_for(total, 256), 256, 0, stream>>>(scratch, dw_oihw, ksplit, Co,
                                                                       a.Co_pad, Ci, RS, accumulate);
