@@ -26,6 +26,9 @@ constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 co
 #ifndef WGRAD_ABL
 #define WGRAD_ABL 0
 #endif
+#ifndef WGRAD_SMALL_TILES
+#define WGRAD_SMALL_TILES 1
+#endif
 #ifndef WGRAD_XCD
 #define WGRAD_XCD 1
 #endif
@@ -1054,7 +1057,7 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     while (tpr * 2 <= CV && tpr * 2 <= 256) tpr *= 2;
     const int rpb = 256 / tpr, gx = (CV + tpr - 1) / tpr;
     int gy = (Mt + 2 * rpb - 1) / (2 * rpb);
-    int cap = 512 / gx;
+    int cap = 512 / gx;  // more blocks only add fp64 statistic atomics (1024 / 2048: forward +11 / +16 % at bs 2)
     if (cap < 1) cap = 1;
     if (gy > cap) gy = cap;
     splitk_epilogue_kernel<<<dim3(gx, gy), 256, 0, stream>>>(
@@ -1106,7 +1109,14 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
   const int RS = R * S;
   const int M = N * Ho * Wo;
   if ((size_t)N * H * W * ldx >= 0x7FFF0000ull) return SEMSEG_EINVAL;  // 32-bit element offsets
-  const bool big = (Ci % 128 == 0) && (Co >= 128);
+  // 128 x 128 tiles need Ci % 128 == 0 and Co >= 128.  With few tiles AND few pixels (small per-GPU batch) K
+  // would be split 20-50 ways to fill the chip, and the partial slabs (ksplit x |dW|) cost more to write and
+  // reduce than the GEMM: 64 x 64 tiles (4x the tiles, 1/4 the slabs) win there and only there.  Measured
+  // (scripts/conv_bench.py 2|4|8): 1x1 with 16 tiles -18 % at M = 7200, -12 % at 14400, -4 % at 28800;
+  // 3x3 with 36 tiles -9 % at 7200, +2 % at 14400; cls.0 (1152 tiles) +10...18 % everywhere.
+  const int t128 = ((Co + 127) / 128) * (Ci / 128) * RS;
+  const bool small_tiles = (RS == 1 && t128 <= 16 && M < 32768) || (RS > 1 && t128 <= 36 && M < 8192);
+  const bool big = (Ci % 128 == 0) && (Co >= 128) && !(WGRAD_SMALL_TILES && small_tiles);
   const int TM = big ? 128 : 64, TN = big ? 128 : 64;
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = scratch; a.ldx = ldx; a.lddy = lddy;
