@@ -6,10 +6,18 @@ def short(n):
     n = n.replace('(anonymous namespace)::', '')
     m = re.match(r'(void )?([\w:<>, ]+?)\(', n)
     return (m.group(2) if m else n).strip()
+def family(k):
+    """Template instantiations that bench.py's KernelTimer reports as one family: the weight-gradient kernel's
+    addressing MODE and the forward/data-gradient kernel's two-level-accumulation flag are dropped."""
+    m = re.match(r'conv_wgrad_kernel<(\d+), (\d+), \d+>', k)
+    if m: return 'conv_wgrad_kernel<%s, %s>' % (m.group(1), m.group(2))
+    m = re.match(r'conv_igemm_kernel<(\d+), (\d+), (true|false), (\d+), (true|false)>', k)
+    if m: return 'conv_igemm_kernel<%s, %s, %s, %s>' % m.groups()[:4]
+    return k
 def agg(path):
     a = collections.defaultdict(lambda: collections.defaultdict(float)); seen = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
-        k = short(r['Kernel_Name'])
+        k = family(short(r['Kernel_Name']))
         a[k][r['Counter_Name']] += float(r['Counter_Value'])
         seen[k][r['Dispatch_Id']] = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
     return {k: dict(c, launches=len(seen[k]), dur_ns=sum(seen[k].values())) for k, c in a.items()}
@@ -36,8 +44,29 @@ json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE |
 shutil.copy(os.path.join(g, tag + "_stats", "bench_kernel_stats.csv"), os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(g, "bench_%s_n1.json" % tag), os.path.join(ROOT, "profiles", tag + "_bench_n1.json"))
 for k, v in sorted(res.items(), key=lambda kv: -(kv[1]['mfma_busy_frac'] or 0))[:8]: print(k, v['mfma_busy_frac'], v['hbm_bytes_per_launch'])
+# bench.py reads the PMC file that was committed when it ran; refresh the two PMC-derived roofline fields of
+# the copied line from THIS round's passes (everything else in the line is as bench.py printed it)
+bp = os.path.join(ROOT, "profiles", tag + "_bench_n1.json")
+d = json.load(open(bp))
+key = family(d["roofline"]["kernel"].split("+")[0].split("(")[0].replace(",", ", "))
+if key in res:
+    d["roofline"]["traffic"] = res[key]["hbm_bytes_per_launch"]
+    d["roofline"]["mfma_busy_frac_pmc"] = res[key]["mfma_busy_frac"]
+    d["roofline"]["traffic_note"] = "traffic / mfma_busy_frac_pmc re-read from profiles/%s_pmc_per_kernel.json after the PMC passes of the same build" % tag
+    json.dump(d, open(bp, "w"))
 d = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_n1.json")))
 print(d['value'], d['ms_per_step'], d['whole_step_frac_of_f32_mfma_peak']); print(d['roofline'])
 for k, v in d['kernel_families'].items(): print(' ', k, v)
 rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv"))))
 for r in rows[:6]: print(short(r['Name']), r['Calls'], "avg us %.1f" % (float(r['AverageNs']) / 1e3))
+# family-level durations of the same rocprofv3 --stats run, comparable with bench.py's kernel_families
+fam = collections.defaultdict(lambda: [0, 0.0])
+for r in rows:
+    k = family(short(r['Name'] + "("))
+    fam[k][0] += int(r['Calls']); fam[k][1] += float(r['TotalDurationNs'])
+with open(os.path.join(ROOT, "profiles", tag + "_bench_family_stats.csv"), "w") as fo:
+    fo.write("family,calls,total_ms,avg_us\n")
+    for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        fo.write('"%s",%d,%.3f,%.2f\n' % (k, c, t / 1e6, t / c / 1e3))
+wg = fam.get('conv_wgrad_kernel<128, 128>'); ru = fam.get('wgrad_reduce_unpack_kernel')
+if wg: print("rocprof family conv_wgrad_kernel<128,128>: avg %.1f us over %d launches (reduce kernel avg %.1f us)" % (wg[1] / wg[0] / 1e3, wg[0], ru[1] / ru[0] / 1e3 if ru else 0))

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): the four rocprofv3 passes behind profiles/<tag>_*; digest with make_profiles.py.
+# PMC passes are separate from each other and carry --kernel-trace only (no sys/runtime/hip/hsa traces).
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out
+rm -rf $out/${tag}_stats $out/${tag}_fetch $out/${tag}_write $out/${tag}_mfma
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o bench -- python bench.py > $out/bench_${tag}_n1.log 2>&1
+grep "^{\"metric\"" $out/bench_${tag}_n1.log | tail -1 > $out/bench_${tag}_n1.json
+B="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch -o pmc -- $B > $out/${tag}_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_write -o pmc -- $B > $out/${tag}_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_mfma -o pmc -- $B > $out/${tag}_mfma.log 2>&1
+# rocprofv3 may nest its output under <hostname>/: flatten to the names make_profiles.py reads
+f=$(find $out/${tag}_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && [ "$f" != "$out/${tag}_stats/bench_kernel_stats.csv" ] && cp "$f" $out/${tag}_stats/bench_kernel_stats.csv
+for d in fetch write mfma; do
+  f=$(find $out/${tag}_$d -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && [ "$f" != "$out/${tag}_$d/pmc_counter_collection.csv" ] && cp "$f" $out/${tag}_$d/pmc_counter_collection.csv
+done
+ls -la $out/${tag}_stats/bench_kernel_stats.csv $out/${tag}_fetch/pmc_counter_collection.csv $out/${tag}_write/pmc_counter_collection.csv $out/${tag}_mfma/pmc_counter_collection.csv
+cat $out/bench_${tag}_n1.json | cut -c1-200
