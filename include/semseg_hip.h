@@ -120,8 +120,13 @@ int semseg_maxpool3x3s2_fwd(const float* x, float* y, uint32_t* idx, int N, int 
                             hipStream_t stream);
 int semseg_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx, float* dx, int N, int H, int W,
                             int C, hipStream_t stream);
+/* y holds the pooled maps of all bins back to back.  With scratch >= semseg_adaptive_avgpool_scratch_floats()
+ * floats the feature map is read once (row sums per (bin, column cell), then a gather over rows) and the
+ * result is deterministic; without it every bin re-reads x and big windows are merged with fp32 atomics. */
 int semseg_adaptive_avgpool_fwd(const float* x, int ldx, float* y, const int* bins, int nbins,
-                                int N, int H, int W, int C, hipStream_t stream);
+                                int N, int H, int W, int C, float* scratch, size_t scratch_floats,
+                                hipStream_t stream);
+size_t semseg_adaptive_avgpool_scratch_floats(const int* bins, int nbins, int N, int H, int C);
 int semseg_adaptive_avgpool_bwd(const float* base, int ldbase, const float* dpool, float* dx,
                                 int lddx, const int* bins, int nbins, int N, int H, int W, int C,
                                 hipStream_t stream);

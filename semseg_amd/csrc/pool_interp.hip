@@ -317,6 +317,120 @@ int semseg_maxpool3x3s2_bwd(const float* dy, const uint32_t* idx, float* dx, int
   return semseg_launch_status();
 }
 
+// ---- PPM pooling in one pass over the feature map (deterministic) --------------------------------------
+// A "slot" is one (bin, column-cell j) pair: sum of bins <= 16 slots.  Stage 1: one workgroup per image row
+// accumulates, for every slot, the sum of the row's pixels that fall into that column window (windows of
+// AdaptiveAvgPool2d may overlap by one pixel, so a pixel can feed two slots of a bin) -> rs[N*H][S][C].
+// Stage 2: each pooled cell sums its slot over the rows of its row window.  x is read once (the per-bin
+// kernel read it once per bin and merged partial windows with fp32 atomics).
+#define POOL_SMAX 16
+struct PoolSlots {
+  int S;
+  int w0[POOL_SMAX], w1[POOL_SMAX];   // column window of the slot
+  int bin[POOL_SMAX], j[POOL_SMAX];   // its bin index (0..nb-1) and column cell
+  int slot_start[5];
+};
+
+__global__ __launch_bounds__(256) void pool_rowsum_kernel(const float* __restrict__ x, int ldx,
+                                                          float* __restrict__ rs, PoolSlots ps, int W,
+                                                          int C) {
+  const int nh = blockIdx.x;
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  f32x4 acc[POOL_SMAX];
+#pragma unroll
+  for (int s = 0; s < POOL_SMAX; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* row = x + (size_t)nh * W * ldx + c;
+  for (int w = 0; w < W; ++w) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + (size_t)w * ldx);
+#pragma unroll
+    for (int s = 0; s < POOL_SMAX; ++s)
+      if (s < ps.S && w >= ps.w0[s] && w < ps.w1[s]) acc[s] += v;   // uniform branch
+  }
+#pragma unroll
+  for (int s = 0; s < POOL_SMAX; ++s)
+    if (s < ps.S) *reinterpret_cast<f32x4*>(rs + ((size_t)nh * ps.S + s) * C + c) = acc[s];
+}
+
+__global__ __launch_bounds__(256) void pool_gather_kernel(const float* __restrict__ rs,
+                                                          float* __restrict__ y, PoolBins pb,
+                                                          PoolSlots ps, int N, int H, int W, int C) {
+  const int cells = pb.cell_start[pb.nb];
+  const int n = blockIdx.x / cells;
+  int cell = blockIdx.x - n * cells;
+  int b = 0;
+  while (b + 1 < pb.nb && cell >= pb.cell_start[b + 1]) ++b;
+  cell -= pb.cell_start[b];
+  const int bin = pb.bin[b];
+  const int i = cell / bin, j = cell - i * bin;
+  const int h0 = (i * H) / bin, h1 = ((i + 1) * H + bin - 1) / bin;
+  const int w0 = (j * W) / bin, w1 = ((j + 1) * W + bin - 1) / bin;
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  const int slot = ps.slot_start[b] + j;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int h = h0; h < h1; ++h)
+    acc += *reinterpret_cast<const f32x4*>(rs + ((size_t)(n * H + h) * ps.S + slot) * C + c);
+  acc *= 1.f / (float)((h1 - h0) * (w1 - w0));
+  *reinterpret_cast<f32x4*>(y + pb.out_off[b] + ((size_t)(n * bin + i) * bin + j) * C + c) = acc;
+}
+
+// dx[n,h,:,c] for one image row: the row's contribution of every slot (sum over the row cells that contain
+// h of dpool / area) is built once in registers, then each pixel adds the slots whose column window holds it.
+__global__ __launch_bounds__(256) void pool_bwd_row_kernel(const float* __restrict__ base, int ldbase,
+                                                           const float* __restrict__ dpool, PoolBins pb,
+                                                           PoolSlots ps, float* __restrict__ dx, int lddx,
+                                                           int H, int W, int C) {
+  const int nh = blockIdx.x;
+  const int n = nh / H, h = nh - n * H;
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  f32x4 g[POOL_SMAX];
+#pragma unroll
+  for (int s = 0; s < POOL_SMAX; ++s) {
+    g[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s < ps.S) {
+      const int b = ps.bin[s], bin = pb.bin[b], j = ps.j[s];
+      for (int i = 0; i < bin; ++i) {
+        const int h0 = (i * H) / bin, h1 = ((i + 1) * H + bin - 1) / bin;
+        if (h < h0 || h >= h1) continue;
+        const float inv = 1.f / (float)((h1 - h0) * (ps.w1[s] - ps.w0[s]));
+        g[s] += *reinterpret_cast<const f32x4*>(dpool + pb.out_off[b] +
+                                                ((size_t)(n * bin + i) * bin + j) * C + c) * inv;
+      }
+    }
+  }
+  for (int w = 0; w < W; ++w) {
+    const size_t pix = (size_t)nh * W + w;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (base) acc = *reinterpret_cast<const f32x4*>(base + pix * ldbase + c);
+#pragma unroll
+    for (int s = 0; s < POOL_SMAX; ++s)
+      if (s < ps.S && w >= ps.w0[s] && w < ps.w1[s]) acc += g[s];
+    *reinterpret_cast<f32x4*>(dx + pix * lddx + c) = acc;
+  }
+}
+
+// slots of a bin set; returns false when there are more than POOL_SMAX (callers fall back)
+static bool make_slots(const int* bins, int nbins, int W, PoolSlots& ps) {
+  int S = 0;
+  for (int b = 0; b < nbins; ++b) {
+    ps.slot_start[b] = S;
+    for (int j = 0; j < bins[b]; ++j) {
+      if (S >= POOL_SMAX) return false;
+      ps.w0[S] = (j * W) / bins[b];
+      ps.w1[S] = ((j + 1) * W + bins[b] - 1) / bins[b];
+      ps.bin[S] = b;
+      ps.j[S] = j;
+      ++S;
+    }
+  }
+  ps.slot_start[nbins] = S;
+  for (int s2 = S; s2 < POOL_SMAX; ++s2) { ps.w0[s2] = ps.w1[s2] = 0; ps.bin[s2] = 0; ps.j[s2] = 0; }
+  ps.S = S;
+  return true;
+}
+
 static int make_bins(const int* bins, int nbins, int N, int C, PoolBins& pb) {
   if (nbins < 1 || nbins > 4) return SEMSEG_EINVAL;
   pb.nb = nbins;
@@ -332,13 +446,29 @@ static int make_bins(const int* bins, int nbins, int N, int C, PoolBins& pb) {
   return SEMSEG_OK;
 }
 
+size_t semseg_adaptive_avgpool_scratch_floats(const int* bins, int nbins, int N, int H, int C) {
+  size_t S = 0;
+  for (int b = 0; b < nbins; ++b) S += (size_t)(bins[b] > 0 ? bins[b] : 0);
+  return S > POOL_SMAX ? 0 : (size_t)N * H * S * C;
+}
+
 // y holds the nbins pooled maps back to back: [N,b0,b0,C][N,b1,b1,C]...
 int semseg_adaptive_avgpool_fwd(const float* x, int ldx, float* y, const int* bins, int nbins,
-                                int N, int H, int W, int C, hipStream_t stream) {
+                                int N, int H, int W, int C, float* scratch, size_t scratch_floats,
+                                hipStream_t stream) {
   if (!x || !y || (C & 3) || (ldx & 3)) return SEMSEG_EINVAL;
   PoolBins pb;
   if (make_bins(bins, nbins, N, C, pb)) return SEMSEG_EINVAL;
   const int cells = N * pb.cell_start[nbins];
+  PoolSlots ps;
+  if (scratch && make_slots(bins, nbins, W, ps) && (size_t)N * H * ps.S * C <= scratch_floats) {
+    // one pass over x (row sums per slot), then a gather over rows: deterministic, x read once
+    dim3 g1(N * H, (C / 4 + 255) / 256);
+    pool_rowsum_kernel<<<g1, 256, 0, stream>>>(x, ldx, scratch, ps, W, C);
+    dim3 g2(cells, (C / 4 + 255) / 256);
+    pool_gather_kernel<<<g2, 256, 0, stream>>>(scratch, y, pb, ps, N, H, W, C);
+    return semseg_launch_status();
+  }
   int nz = 1;
   if (cells * ((C / 4 + 255) / 256) < 512 && H >= 16) nz = 8;
   if (nz > 1) {
@@ -357,6 +487,12 @@ int semseg_adaptive_avgpool_bwd(const float* base, int ldbase, const float* dpoo
   if (!dpool || !dx || (C & 3) || (lddx & 3) || (base && (ldbase & 3))) return SEMSEG_EINVAL;
   PoolBins pb;
   if (make_bins(bins, nbins, N, C, pb)) return SEMSEG_EINVAL;
+  PoolSlots ps;
+  if (make_slots(bins, nbins, W, ps)) {
+    dim3 grid(N * H, (C / 4 + 255) / 256);
+    pool_bwd_row_kernel<<<grid, 256, 0, stream>>>(base, ldbase, dpool, pb, ps, dx, lddx, H, W, C);
+    return semseg_launch_status();
+  }
   dim3 grid(N * H * W, (C / 4 + 255) / 256);
   adaptive_pool_bwd_kernel<<<grid, 256, 0, stream>>>(base, ldbase, dpool, pb, dx, lddx, N, H, W, C);
   return semseg_launch_status();

@@ -537,7 +537,7 @@ class Engine:
         N, H, W, C = x4.N, x4.H, x4.W, x4.C
         tot = sum(N * b * b * C for b in bins)
         pooled = self.buf((tot,), tag="pooled")
-        ops.adaptive_avgpool_fwd(x4.data, x4.ld, pooled, bins, N, H, W, C)
+        ops.adaptive_avgpool_fwd(x4.data, x4.ld, pooled, bins, N, H, W, C, scratch=self.scratch())
         off = 0
         pacts = []
         c0 = C

@@ -184,9 +184,13 @@ def _bins(bins):
     return ctypes.addressof(_bins_cache[key])
 
 
-def adaptive_avgpool_fwd(x, ldx, y, bins, N, H, W, C):
+def adaptive_avgpool_scratch_floats(bins, N, H, C):
+    return int(lib.semseg_adaptive_avgpool_scratch_floats(_bins(bins), len(bins), N, H, C))
+
+
+def adaptive_avgpool_fwd(x, ldx, y, bins, N, H, W, C, scratch=None):
     _ck(lib.semseg_adaptive_avgpool_fwd(_p(x), ldx, _p(y), _bins(bins), len(bins), N, H, W, C,
-                                        _stream()), "adaptive_avgpool_fwd")
+                                        *_scr(scratch), _stream()), "adaptive_avgpool_fwd")
 
 
 def adaptive_avgpool_bwd(base, ldbase, dpool, dx, lddx, bins, N, H, W, C):

@@ -266,11 +266,23 @@ def test_adaptive_pool(H, report):
     xb[..., :C] = nhwc(x.detach().float()).to(DEV)
     tot = sum(N * b * b * C for b in bins)
     y = torch.empty(tot, device=DEV)
-    ops.adaptive_avgpool_fwd(xb, ld, y, bins, N, H, W, C)
+    ops.adaptive_avgpool_fwd(xb, ld, y, bins, N, H, W, C)            # per-bin kernel (no scratch)
     off, es = 0, []
     for b, o in zip(bins, outs):
         n = N * b * b * C
         es.append(relerr(nchw(y[off:off + n].view(N, b, b, C)), o))
+        off += n
+    # single-pass path (what the engine runs): same result, and bit-identical from run to run
+    scr = torch.empty(ops.adaptive_avgpool_scratch_floats(bins, N, H, C), device=DEV)
+    assert scr.numel() == N * H * sum(bins) * C
+    y1, y2 = torch.empty(tot, device=DEV), torch.empty(tot, device=DEV)
+    ops.adaptive_avgpool_fwd(xb, ld, y1, bins, N, H, W, C, scratch=scr)
+    ops.adaptive_avgpool_fwd(xb, ld, y2, bins, N, H, W, C, scratch=scr)
+    assert torch.equal(y1, y2)
+    off = 0
+    for b, o in zip(bins, outs):
+        n = N * b * b * C
+        es.append(relerr(nchw(y1[off:off + n].view(N, b, b, C)), o))
         off += n
     dp = torch.cat([nhwc(d.float()).reshape(-1) for d in dps]).to(DEV)
     dx = torch.empty(N, H, W, C, device=DEV)
