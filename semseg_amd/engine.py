@@ -324,9 +324,9 @@ class Engine:
         if side:
             st = self._side_stream()
             st.wait_stream(torch.cuda.current_stream())
+            self._side_used = True      # before the block: _wgrad may hand a gradient bucket to the communicator
             with torch.cuda.stream(st):
                 self._wgrad(x, y, cl, m, self._scratch2())
-            self._side_used = True
         else:
             self._wgrad(x, y, cl, m, self.scratch())
         if x.name != "input":
@@ -376,6 +376,19 @@ class Engine:
     def _ready(self, plist):
         if self.grads_ready_hook is not None:
             self.grads_ready_hook(plist)
+
+    def order_after_all_producers(self):
+        """Gradients are written by two streams (the main one and the weight-gradient side stream), and a
+        collective is only ordered after the stream that is current when it is issued.  Make that stream
+        wait for everything the other one has enqueued so far; call this right before a gradient bucket
+        is handed to the communicator (the call may come from either stream)."""
+        if self._side is None or not self._side_used:
+            return
+        cur = torch.cuda.current_stream()
+        if cur == self._side:
+            cur.wait_stream(self._main)
+        else:
+            cur.wait_stream(self._side)
 
     def _sync(self, t):
         if (self.sync_bn or self.force_sync_bn) and self.dist_on:
@@ -685,6 +698,7 @@ class Engine:
             pass
         self._reset_grad_flags()
         self._f64_zero_sums()
+        self._main = torch.cuda.current_stream()
         self.ce_bwd(self._rec_main, gmain)
         self.ce_bwd(self._rec_aux, gaux)
         for fn in reversed(self.tape):

@@ -107,6 +107,8 @@ class Trainer:
             e._pending[bi] -= 1
             if e._pending[bi] == 0:
                 lo, hi, _ = e._buckets[bi]
+                # the bucket's gradients come from BOTH the main and the side stream, whichever issues this
+                e.order_after_all_producers()
                 e._works.append(dist.all_reduce(e.flat_grad[lo:hi], group=self.grad_group, async_op=True))
 
     # ------------------------------------------------------------------ one optimisation step

@@ -96,3 +96,33 @@ def test_reference_train_wrapping_sequence(report):
                ["%.4f" % v for v in losses])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lagging", ["side", "main"])
+def test_bucket_collectives_wait_for_both_gradient_streams(lagging, report):
+    """Gradients of one all-reduce bucket are written by two HIP streams (main: BN parameter gradients, stem
+    and large-grid weight gradients; side: weight gradients of small grids).  A collective is ordered after the
+    stream that is current when it is issued, so the trainer joins the other stream first
+    (Engine.order_after_all_producers).  tests/bucket_order_worker.py replaces the collective by a snapshot
+    taken with that ordering rule and slows one stream down with device sleeps.
+    * with the join: no snapshot may be stale, whichever stream lags;
+    * negative control (join disabled = the code before the fix): buckets completed by a side-stream weight
+      gradient are still clean (every side launch already waits on the main stream), but the LAST bucket is
+      completed by the stem weight gradient on the main stream, and with the side stream lagging its snapshot
+      is stale (786 432 of 794 304 elements) - that was a real bug of the N > 1 path.
+    Runs in a fresh process: in a long-lived one, streams can alias onto one hardware queue and hide the race."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bucket_order_worker.py"), lagging],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    report("bucket ordering, %s stream lagging: issued from %s; stale elements per bucket with the join %s, "
+           "without it (control) %s" % (lagging, d["issued_from"], d["stale_with_join"], d["stale_without_join"]))
+    assert sum(d["stale_with_join"]) == 0
+    assert d["issued_from"][-1] == "main" and "side" in d["issued_from"]
+    assert sum(d["stale_without_join"][:-1]) == 0
+    if lagging == "side":
+        assert d["stale_without_join"][-1] > 0, "control did not expose the race"
+    else:
+        assert d["stale_without_join"][-1] == 0
