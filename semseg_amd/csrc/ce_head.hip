@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void ce_bwd_cell_kernel(const float* __restric
   f32x4 a[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (c < C) {
+  if (c < C && part < PARTS) {   // CG = 40 leaves 16 idle threads (part == PARTS)
     const float* bz = z + (size_t)n * h * w * ld + c;
     for (int q = part; q < cnt; q += PARTS) {
       const int oh = oh_lo + q / nw, ow = ow_lo + q % nw;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void ce_bwd_cell_kernel(const float* __restric
   for (int q = 0; q < 4; ++q) red[q][threadIdx.x] = a[q];
   __syncthreads();
   if (part == 0 && c < CP) {
-    float* o = cellbuf + ((((size_t)n * ch + cr) * cw + cc) * 4) * CP + c;
+    float* o = cellbuf + ((((size_t)n * ch + cr) * cw + cc) * 4) * CP + c;   // (threads >= PARTS * CG hold zeros)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 r = red[q][cg];
@@ -324,6 +324,7 @@ int semseg_ce_head_bwd(const float* scores, int ld, const long long* label, cons
     if (cv <= 8) CE_CELL(8);
     else if (cv <= 16) CE_CELL(16);
     else if (cv <= 32) CE_CELL(32);
+    else if (cv <= 40) CE_CELL(40);   // 150 classes = 38 float4: 6 pixels x 40 lanes instead of 4 x 64
     else if (cv <= 64) CE_CELL(64);
     else CE_CELL(128);
 #undef CE_CELL
