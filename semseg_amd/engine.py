@@ -694,8 +694,6 @@ class Engine:
 
     def backward(self, gmain, gaux):
         """Replays the tape; on return every parameter gradient is in self.grad_views."""
-        for t in self._bufs.values():
-            pass
         self._reset_grad_flags()
         self._f64_zero_sums()
         self._main = torch.cuda.current_stream()
