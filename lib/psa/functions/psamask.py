@@ -17,33 +17,37 @@ def _check(t, what):
         raise TypeError("psa_mask: %s must be float32 (lib/psa/src/cpu/psamask.cpp:117)" % what)
 
 
+def _geometry(input, psa_type, mask_H_, mask_W_):
+    """Argument checks of psamask.py:9-17 -> (N, mask channels, H, W, mask_H, mask_W, half_h, half_w)."""
+    assert psa_type in [0, 1]  # 0 collect, 1 distribute
+    assert (mask_H_ is None) == (mask_W_ is None)
+    n, chans, fh, fw = input.size()
+    if mask_H_ is None:
+        mask_H_, mask_W_ = 2 * fh - 1, 2 * fw - 1
+    assert mask_H_ % 2 == 1 and mask_W_ % 2 == 1
+    assert chans == mask_H_ * mask_W_
+    return n, chans, fh, fw, mask_H_, mask_W_, (mask_H_ - 1) // 2, (mask_W_ - 1) // 2
+
+
 class PSAMask(Function):
     @staticmethod
     def forward(ctx, input, psa_type=0, mask_H_=None, mask_W_=None):
-        assert psa_type in [0, 1]  # 0-col, 1-dis
-        assert (mask_H_ is None and mask_W_ is None) or (mask_H_ is not None and mask_W_ is not None)
-        num_, channels_, feature_H_, feature_W_ = input.size()
-        if mask_H_ is None and mask_W_ is None:
-            mask_H_, mask_W_ = 2 * feature_H_ - 1, 2 * feature_W_ - 1
-        assert (mask_H_ % 2 == 1) and (mask_W_ % 2 == 1)
-        assert channels_ == mask_H_ * mask_W_
+        geo = _geometry(input, psa_type, mask_H_, mask_W_)
+        n, chans, fh, fw, mh, mw, hh, hw = geo
         _check(input, "input")
-        half_h, half_w = (mask_H_ - 1) // 2, (mask_W_ - 1) // 2
-        output = torch.zeros([num_, feature_H_ * feature_W_, feature_H_, feature_W_], dtype=input.dtype,
-                             device=input.device)
-        ops.psamask_forward(psa_type, input.contiguous(), output, num_, feature_H_, feature_W_, mask_H_,
-                            mask_W_, half_h, half_w)
-        ctx.cfg = (psa_type, num_, channels_, feature_H_, feature_W_, mask_H_, mask_W_, half_h, half_w)
+        output = torch.zeros((n, fh * fw, fh, fw), dtype=input.dtype, device=input.device)
+        ops.psamask_forward(psa_type, input.contiguous(), output, n, fh, fw, mh, mw, hh, hw)
+        ctx.cfg = (psa_type,) + geo
         return output
 
     @staticmethod
     def backward(ctx, grad_output):
-        psa_type, num_, channels_, fH, fW, mH, mW, half_h, half_w = ctx.cfg
+        psa_type, n, chans, fh, fw, mh, mw, hh, hw = ctx.cfg
         _check(grad_output, "grad_output")
-        # the reference assumes a dense gradient (a stride-0 grad makes it read garbage)
+        # the reference assumes a dense gradient (SURVEY.md section 4: a stride-0 grad makes it read garbage)
         grad_output = grad_output.contiguous()
-        grad_input = torch.zeros([num_, channels_, fH, fW], dtype=grad_output.dtype, device=grad_output.device)
-        ops.psamask_backward(psa_type, grad_output, grad_input, num_, fH, fW, mH, mW, half_h, half_w)
+        grad_input = torch.zeros((n, chans, fh, fw), dtype=grad_output.dtype, device=grad_output.device)
+        ops.psamask_backward(psa_type, grad_output, grad_input, n, fh, fw, mh, mw, hh, hw)
         return grad_input, None, None, None
 
 
