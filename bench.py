@@ -217,7 +217,8 @@ def main():
                 for k, v in pmc.items():
                     if k.replace(" ", "") == key:
                         roof["traffic"] = v["hbm_bytes_per_launch"]
-                        roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_pmc_per_kernel.json)"
+                        roof["traffic_unit"] = ("bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_pmc_per_kernel.json"
+                                                + (")" if world == 1 else "; collected at n_gpus=1, per-GPU batch 16)"))
                         roof["mfma_busy_frac_pmc"] = v.get("mfma_busy_frac")
             except Exception:
                 pass
