@@ -5,10 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "semseg_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_variants")
 VARIANTS = {   # last used set; earlier sets are listed in DESIGN.md section 8.1
-    "base_a": [],
-    "abl1_noglobal": ["-DWGRAD_ABL=1"],
-    "abl2_nolds_store": ["-DWGRAD_ABL=2"],
-    "base_b": [],
+    "occ2_a": [],
+    "occ3_1x1_a": ["-DCONV_OCC_1X1=3"],
+    "occ2_b": [],
+    "occ3_1x1_b": ["-DCONV_OCC_1X1=3"],
 }
 SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "infer.hip", "optim.hip"]
 if sys.argv[1] == "build":
@@ -24,5 +24,5 @@ else:
     for tag in VARIANTS:
         env = dict(os.environ, SEMSEG_HIP_LIB=os.path.join(OUT, "lib_%s.so" % tag))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "conv_bench.py")], env=env, capture_output=True, text=True)
-        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("l1 conv3", "l3 conv1", "l3 conv2", "l3 conv3", "l4 conv", "cls.0", "weighted"))]
+        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("l1 conv", "l3 conv1", "l3 conv3", "l4 conv1", "l4 conv3", "weighted"))]
         print("==", tag); print("\n".join(lines)); sys.stdout.flush()

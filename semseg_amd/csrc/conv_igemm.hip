@@ -41,6 +41,9 @@ constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 co
 #ifndef CONV_OCC
 #define CONV_OCC 2
 #endif
+#ifndef CONV_OCC_1X1
+#define CONV_OCC_1X1 2
+#endif
 #ifndef CONV_DBUF
 #define CONV_DBUF 0
 #endif
@@ -104,7 +107,7 @@ struct ConvArgs {
 // carry an out-of-range offset, which the buffer unit returns as 0) plus one scalar offset per K-step —
 // no per-K-step address VALU between the MFMAs at all.
 template <int BM, int BN, bool TR, int RS_T, bool TL>
-__global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OCC) void conv_igemm_kernel(const ConvArgs p) {
   // BM/64 x 2 waves, each a 64 x (BN/2) sub-tile of 32x32 MFMA blocks
   constexpr int NT = BM * 2;                 // threads
   constexpr int RSTEP = NT / 8;              // tile rows staged per pass (8 lanes x 16 B per row)
