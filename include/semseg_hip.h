@@ -147,6 +147,11 @@ int semseg_ce_head_bwd(const float* scores, int ld, const long long* label, cons
                        int lddz, int accumulate, int N, int h, int w, int H, int W, int C,
                        int ignore_index, float* scratch, size_t scratch_floats, hipStream_t stream);
 
+/* Counts targets that are neither ignore_index nor in [0, C): torch's CrossEntropyLoss (tool/train.py:121) raises
+ * on those; the fused head treats them as ignored, so callers validate (the engine does on its first step). */
+int semseg_label_check(const long long* label, size_t n, int C, int ignore_index,
+                       unsigned long long* bad_count_dev, hipStream_t stream);
+
 /* ---- PSA head on the engine's pixel-major layout (model/psanet.py:53-98).
  * psamask_nhwc: attention map [N, H*W, taps(ldm)] <-> affinity rows aff[n, q, p] (lda >= H*W), same
  * index maps as semseg_psamask_* (lib/psa/src/cpu/psamask.cpp:11-113); out-of-window entries = 0.

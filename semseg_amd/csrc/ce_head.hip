@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z
   __syncthreads();
   if (part == 0 && c < lddz) {
     for (int pp = 1; pp < PARTS; ++pp) a += red[pp * CG + cg];
-    float scale = gmul / (float)acc[1];
-    if (gloss) scale *= gloss[0];
+    // no valid pixel: torch's nll_loss backward leaves grad_input at 0 (only the loss is NaN)
+    float scale = acc[1] > 0.0 ? gmul / (float)acc[1] : 0.f;
+    if (gloss && acc[1] > 0.0) scale *= gloss[0];
     a *= scale;
     float* o = dz + (size_t)pixl * lddz + c;
     if (accumulate) a += *reinterpret_cast<const f32x4*>(o);
@@ -259,8 +260,9 @@ __global__ __launch_bounds__(256) void ce_bwd_gather_cells_kernel(const float* _
   const int ch = max(h - 1, 1), cw = max(w - 1, 1);
   const int CV = CP >> 2;
   const size_t total = (size_t)N * h * w * CV;
-  float scale = gmul / (float)acc[1];
-  if (gloss) scale *= gloss[0];
+  // no valid pixel: torch's nll_loss backward leaves grad_input at 0 (only the loss is NaN)
+  float scale = acc[1] > 0.0 ? gmul / (float)acc[1] : 0.f;
+  if (gloss && acc[1] > 0.0) scale *= gloss[0];
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int c = (int)(idx % CV) * 4;
     size_t t = idx / CV;
@@ -285,9 +287,33 @@ __global__ __launch_bounds__(256) void ce_bwd_gather_cells_kernel(const float* _
   }
 }
 
+// counts targets that are neither ignore_index nor a class id (torch raises / device-asserts on those)
+__global__ __launch_bounds__(256) void label_check_kernel(const long long* __restrict__ label, size_t n,
+                                                          int C, int ignore_index,
+                                                          unsigned long long* __restrict__ bad) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const long long y = label[i];
+    if (y != (long long)ignore_index && (y < 0 || y >= C)) ++c;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(bad, c);
+}
+
 }  // namespace
 
 extern "C" {
+
+int semseg_label_check(const long long* label, size_t n, int C, int ignore_index,
+                       unsigned long long* bad_count_dev, hipStream_t stream) {
+  if (!label || !bad_count_dev || C <= 0) return SEMSEG_EINVAL;
+  if (hipMemsetAsync(bad_count_dev, 0, sizeof(unsigned long long), stream) != hipSuccess) return SEMSEG_ELAUNCH;
+  size_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  label_check_kernel<<<(int)g, 256, 0, stream>>>(label, n, C, ignore_index, bad_count_dev);
+  return semseg_launch_status();
+}
 
 int semseg_ce_head_fwd(const float* scores, int ld, const long long* label, float* lse,
                        long long* pred, double* acc2, float* loss, int N, int h, int w, int H, int W,

@@ -62,6 +62,15 @@ class KernelTimer:
                 "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
 
 
+class TapeOp:
+    """One backward step of the tape: `fn()` launches it; `kind` + `ctx` name the operands so a test hook
+    (Engine.tape_hook) can snapshot them around the launch and re-derive the result independently."""
+    __slots__ = ("kind", "fn", "ctx")
+
+    def __init__(self, kind, fn, ctx):
+        self.kind, self.fn, self.ctx = kind, fn, ctx
+
+
 class Act:
     """NHWC activation view: `data` starts at the first valid channel; `ld` = channel stride."""
     __slots__ = ("data", "N", "H", "W", "C", "ld", "grad", "ginit", "name")
@@ -143,6 +152,17 @@ class Engine:
         self._scr2 = None
         self._side_used = False
         self._mod_ids = tuple(id(m) for m in model.modules())
+        self._labels_checked = False
+        self.tape_hook = None  # callable(TapeOp) that must call op.fn(); set by tests only
+
+    def push(self, kind, fn, **ctx):
+        self.tape.append(TapeOp(kind, fn, ctx))
+
+    def _run(self, op):
+        if self.tape_hook is not None:
+            self.tape_hook(op)
+        else:
+            op.fn()
 
     def params_stale(self):
         """True when the module tree changed under us (convert_sync_batchnorm, .to(device), ...)."""
@@ -173,7 +193,8 @@ class Engine:
                 if m is first:
                     self.convs[m] = None  # stem: direct kernel, no packed panel
                 else:
-                    self.convs[m] = ConvL(m, self.device)
+                    # eval engines never run a data-gradient: no second packed panel (halves their weight copy)
+                    self.convs[m] = ConvL(m, self.device, need_dgrad=self.training)
             elif isinstance(m, nn.modules.batchnorm._BatchNorm):
                 self.bns[m] = BNL(m, self)
 
@@ -234,12 +255,14 @@ class Engine:
             for i, (m, cl) in enumerate(items):
                 pk = cl.pk
                 RS = pk.R * pk.S
-                arr[i] = Desc(m.weight.data_ptr(), pk.w_fwd.data_ptr(), pk.w_dgrad.data_ptr(), pk.Co, pk.Ci, RS,
+                arr[i] = Desc(m.weight.data_ptr(), pk.w_fwd.data_ptr(),
+                              0 if pk.w_dgrad is None else pk.w_dgrad.data_ptr(), pk.Co, pk.Ci, RS,
                               pk.Co_pad, pk.Ci_pad, pk.Kc_dgrad)
                 starts.append(blk)
                 blk += (pk.Co_pad * pk.Ci * RS + 1023) // 1024
-                starts.append(blk)
-                blk += (pk.Ci_pad * pk.Kc_dgrad * RS + 1023) // 1024
+                starts.append(blk)   # a zero-length segment (no dgrad panel) is never selected by the block search
+                if pk.w_dgrad is not None:
+                    blk += (pk.Ci_pad * pk.Kc_dgrad * RS + 1023) // 1024
             raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
             self._pack_descs = torch.from_numpy(raw).to(self.device)
             self._pack_starts = torch.tensor(starts, dtype=torch.int32, device=self.device)
@@ -289,7 +312,7 @@ class Engine:
                          nslot=ops.NSLOT, scratch=self.scratch())
         self._t1(ev)
         if self.training:
-            self.tape.append(lambda: self._conv_bwd(x, out, cl, m))
+            self.push("conv", lambda: self._conv_bwd(x, out, cl, m), x=x, y=out, cl=cl, m=m)
         return out
 
     def _wgrad(self, x, y, cl, m, scratch):
@@ -437,7 +460,9 @@ class Engine:
                      res=None if res is None else res.data, ldres=0 if res is None else res.ld,
                      dropmask=dropmask)
         if self.training:
-            self.tape.append(lambda: self._bn_act_bwd(y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt))
+            self.push("bn_act", lambda: self._bn_act_bwd(y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt),
+                      y=y, bm=bm, bl=bl, relu=relu, res=res, y2=y2, bm2=bm2, bl2=bl2, dropmask=dropmask, out=out,
+                      cnt=cnt)
         return out
 
     def _bn_act_bwd(self, y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt):
@@ -486,7 +511,7 @@ class Engine:
             def bwd():
                 ops.stem_conv_wgrad(x_nchw, y0.grad, self.grad_views[c0.weight], N, H, W)
                 self._ready([c0.weight])
-            self.tape.append(bwd)
+            self.push("stem_wgrad", bwd, x=x_nchw, y=y0, m=c0)
         a = self.bn_act(y0, l0[1])
         a = self.conv_bn(a, l0[3], l0[4])
         a = self.conv_bn(a, l0[6], l0[7])
@@ -500,7 +525,7 @@ class Engine:
                 ga = self.grad_of(a)
                 ops.maxpool_bwd(p.grad, idx, ga, N, a.H, a.W, a.C)
                 a.ginit = True
-            self.tape.append(bwd_pool)
+            self.push("maxpool", bwd_pool, x=a, y=p, idx=idx)
         return p
 
     def _st(self, bm):
@@ -567,7 +592,7 @@ class Engine:
                     gab = self.grad_of(ab)
                     ops.bilinear_bwd(cat.grad[..., c0:], cat.ld, gab, ab.ld, N, b, b, H, W, ab.C)
                     ab.ginit = True
-                self.tape.append(bwd_up)
+                self.push("upsample", bwd_up, x=ab, dy=lambda c0=c0: cat.grad[..., c0:], lddy=cat.ld, Ho=H, Wo=W)
             c0 += ab.C
         if self.training:
             dpool = self.buf((tot,), tag="dpool")
@@ -584,7 +609,7 @@ class Engine:
                 x4.grad = gx
                 x4.ginit = True
             # must run after every branch backward => insert *before* the branch ops on the tape
-            self._ppm_pool_bwd = bwd_pool
+            self._ppm_pool_bwd = TapeOp("ppm_pool", bwd_pool, dict(cat=cat, dpool=dpool, bins=bins, C=C))
         return cat
 
     def head(self, x, seq, tag):
@@ -685,6 +710,14 @@ class Engine:
         y = y.contiguous()
         h, w = self.out_hw()
         assert tuple(y.shape) == (self.N, h, w), "target must be [N,%d,%d]" % (h, w)
+        if not self._labels_checked or os.environ.get("SEMSEG_CHECK_LABELS") == "1":
+            # torch's CrossEntropyLoss raises on class ids outside [0, C); the fused head would silently ignore
+            # them.  Checked on this engine's first step (one sync), every step with SEMSEG_CHECK_LABELS=1.
+            nbad = ops.label_check(y, self.model.cls[4].weight.shape[0], ignore_index)
+            if nbad:
+                raise IndexError("Target out of bounds: %d label(s) are neither ignore_index=%d nor in [0, %d)"
+                                 % (nbad, ignore_index, self.model.cls[4].weight.shape[0]))
+            self._labels_checked = True
         x_tmp, feat = self._features(x)
         scores = self.head(feat, self.model.cls, "m")
         aux = self.head(x_tmp, self.model.aux, "a")
@@ -697,10 +730,10 @@ class Engine:
         self._reset_grad_flags()
         self._f64_zero_sums()
         self._main = torch.cuda.current_stream()
-        self.ce_bwd(self._rec_main, gmain)
-        self.ce_bwd(self._rec_aux, gaux)
-        for fn in reversed(self.tape):
-            fn()
+        self._run(TapeOp("ce", lambda: self.ce_bwd(self._rec_main, gmain), dict(rec=self._rec_main, gloss=gmain, gmul=1.0)))
+        self._run(TapeOp("ce", lambda: self.ce_bwd(self._rec_aux, gaux), dict(rec=self._rec_aux, gloss=gaux, gmul=1.0)))
+        for op in reversed(self.tape):
+            self._run(op)
         if self._side_used:
             torch.cuda.current_stream().wait_stream(self._side)   # join the weight-gradient stream
             self._side_used = False

@@ -43,13 +43,21 @@ class _NetFunction(torch.autograd.Function):
 class HipSegModule(nn.Module):
     kind = "psp"
 
+    MAX_ENGINES = 6   # each engine owns its activation buffers and packed weights: bound the cache (LRU)
+
     def _engine(self, x, training):
+        if next(self.parameters(), None) is None:
+            # nn.DataParallel replicas carry no nn.Parameters (tool/train.py's non-distributed multi-GPU path)
+            raise RuntimeError("semseg_amd modules cannot run as multi-GPU nn.DataParallel replicas: use one process "
+                               "per GPU with DistributedDataParallel (tool/train.py multiprocessing_distributed)")
         key = (tuple(x.shape), bool(training), x.device.index)
         cache = self.__dict__.setdefault("_engines", {})
-        eng = cache.get(key)
+        eng = cache.pop(key, None)
         if eng is None or eng.device != x.device or eng.params_stale():
             eng = Engine(self, x.shape[0], x.shape[2], x.shape[3], training, self.kind)
-            cache[key] = eng
+        cache[key] = eng                      # most recently used last
+        while len(cache) > self.MAX_ENGINES:
+            cache.pop(next(iter(cache)))      # evict the least recently used shape
         return eng
 
     def _ignore_index(self):

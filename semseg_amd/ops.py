@@ -229,6 +229,14 @@ def ce_head_bwd(scores, ld, label, lse, acc2, grad_loss, grad_mul, dscores, lddz
                                ignore_index, *_scr(scratch), _stream()), "ce_head_bwd")
 
 
+def label_check(label, C, ignore_index):
+    """Number of targets that are neither ignore_index nor a class id (synchronises)."""
+    assert label.dtype == torch.int64 and label.is_cuda and label.is_contiguous()
+    bad = torch.zeros(1, dtype=torch.int64, device=label.device)
+    _ck(lib.semseg_label_check(_p(label), label.numel(), C, ignore_index, _p(bad), _stream()), "label_check")
+    return int(bad.item())
+
+
 def sgd_step(w, g, mom, n, lr, momentum, weight_decay, grad_scale=1.0, first_step=False, lr_dev=None):
     _ck(lib.semseg_sgd_step(_p(w), _p(g), _p(mom), n, float(lr), _p(lr_dev), momentum, weight_decay,
                             grad_scale, int(first_step), _stream()), "sgd_step")

@@ -37,7 +37,7 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
                 g = eng.grad_of(xr)
                 ops.bilinear_bwd(xs.grad, xs.ld, g, xr.ld, N, H, W, h, w, xr.C)
                 xr.ginit = True
-            eng.tape.append(bwd_shrink)
+            eng.push("upsample", bwd_shrink, x=xr, dy=lambda: xs.grad, lddy=xs.ld, Ho=h, Wo=w)
     else:
         h, w = H, W
         xs = eng.conv_bn(x4, red[0], red[1], out=_padded_act(eng, N, h, w, red[0].weight.shape[0], "psa_xs"))
@@ -94,7 +94,8 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
                     ops.psamask_nhwc_backward(typ, daff, P, gym, ym.ld, N, h, w, mH, mW)
             ym.ginit = True
         # appended last => runs first in backward, before the attention convs' backward
-        eng.tape.append(bwd_contract)
+        eng.push("psa_contract", bwd_contract, xs=xs, ym=ym, aff=aff, zcat=zcat, zoff=zoff, typ=typ, psa=psa, P=P,
+                 h=h, w=w, alpha=alpha)
     return h, w
 
 
@@ -122,19 +123,19 @@ def psa_forward(eng, x4, cat):
                 g = eng.grad_of(ap)
                 ops.bilinear_bwd(cat.grad[..., 2048:], cat.ld, g, ap.ld, N, h, w, Ho, Wo, ap.C)
                 ap.ginit = True
-            eng.tape.append(bwd_expand)
+            eng.push("upsample", bwd_expand, x=ap, dy=lambda: cat.grad[..., 2048:], lddy=cat.ld, Ho=Ho, Wo=Wo)
     else:
         eng.conv_bn(zcat, m.proj[0], m.proj[1], out=dst)
         if eng.training:
             def link2():
                 dst.grad = cat.grad[..., 2048:]
                 dst.ginit = True
-            eng.tape.append(link2)
+            eng.push("link", link2)
     if eng.training:
         def link():
             # cls' data-gradient wrote cat.grad; its first 2048 channels are x4's gradient so far:
             # the reduce convs' data-gradients accumulate into it
             x4.grad = cat.grad
             x4.ginit = True
-        eng.tape.append(link)  # appended last => runs first among the PSA backward closures
+        eng.push("link", link)  # appended last => runs first among the PSA backward closures
     return cat

@@ -115,7 +115,15 @@ class Trainer:
     def step(self, x, y, lr=None):
         """x [N,3,H,W] fp32 cuda, y [N,h,w] int64 cuda (per-rank shard).  Returns (pred, main, aux)."""
         lr = self.base_lr if lr is None else lr
+        # the parameters must still be views of flat_w (model.to()/half()/load_state_dict(assign=True) break that
+        # silently: SGD would then update a buffer nobody reads)
+        for p in (self.params[0], self.params[-1]):
+            if p.data_ptr() != self.flat_w.data_ptr() + 4 * self.offsets[p][0]:
+                raise RuntimeError("model parameters no longer alias the Trainer's flat buffer (the model was moved / "
+                                   "re-assigned after Trainer(model)); build a new Trainer")
         e = self.engine(x)
+        if e.params_stale():
+            raise RuntimeError("the module tree changed after the Trainer built its engine; build a new Trainer")
         pred, main_loss, aux_loss = e.forward_train(x, y, self.ignore_index)
         if self.dist_on:
             e._pending = [len(ps) for _, _, ps in e._buckets]

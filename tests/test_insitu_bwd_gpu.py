@@ -1,0 +1,79 @@
+"""In-situ per-op backward parity at the BASELINE.json shapes.
+
+One real train step of PSPNet-101 473x473 / PSANet-101 465x465 (per-GPU batch 2, the 8-GPU shard of the metric
+configuration) runs on the HIP engine with tests/insitu.py installed as the tape hook: every backward op is
+recomputed on the CPU in fp64 AND fp32 from the operands the HIP path itself used, so ReLU-mask flips and the
+conditioning of the 100-layer network cannot hide (or fake) a kernel error.  Criterion for every dgrad, wgrad,
+BatchNorm-backward, upsample/pool adjoint, CE-backward and PSA adjoint:
+    err_hip <= 3 x err_cpu_fp32 + 2e-7        (err = max|a - ref_fp64| / max|ref_fp64|)
+The train-mode losses of the same step are checked against the CPU oracle (oracle/segnet.py, pinned to the imported
+reference) at 1e-5, which also covers "PSPNet-101 473^2 train losses vs oracle".
+"""
+import os
+
+import pytest
+import torch
+
+from test_model_gpu import build, inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(report, name, arch, layers, classes, size, batch, psa_cfg=None, oracle_loss=True):
+    from oracle import segnet
+    from insitu import run_insitu
+    kw = dict(psa_cfg) if psa_cfg else {}
+    m, sd = build(arch, layers, classes, **kw)
+    x, y = inputs(batch, size, classes)
+    m = m.cuda().train()
+    chk, ml, al = run_insitu(m, x.cuda(), y.cuda(), report)
+    report("in-situ backward parity, %s: %d quantities over %d ops\n%s"
+           % (name, len(chk.rows), len({(r[0], r[1]) for r in chk.rows}), chk.summary()))
+    if oracle_loss:
+        with torch.no_grad():
+            _, ml_ref, al_ref = segnet.forward({k: v.clone() for k, v in sd.items()}, x, layers, arch, training=True,
+                                               y=y, psa_cfg=psa_cfg)
+        e_ml = abs(ml - ml_ref.item()) / abs(ml_ref.item())
+        e_al = abs(al - al_ref.item()) / abs(al_ref.item())
+        report("%s: train losses vs oracle main %.2e aux %.2e" % (name, e_ml, e_al))
+        assert e_ml < 1e-5 and e_al < 1e-5
+    bad = chk.failures()
+    assert not bad, "ops outside 3x the CPU-fp32 noise: %s" % (bad[:8],)
+    return chk
+
+
+def test_insitu_pspnet50_small(report):
+    """Fast variant (every op kind of the PSPNet path, 73x73)."""
+    chk = _case(report, "pspnet50 c21 73^2 b2", "psp", 50, 21, 73, 2)
+    kinds = {r[0] for r in chk.rows}
+    assert {"conv", "bn_act", "stem", "maxpool", "upsample", "ppm_pool", "ce"} <= kinds
+
+
+def test_insitu_psanet50_small(report):
+    cfg = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=9, mask_w=9, normalization_factor=1.0,
+               psa_softmax=True)
+    chk = _case(report, "psanet50 c19 65^2 b2", "psa", 50, 19, 65, 2, psa_cfg=cfg)
+    assert "psa" in {r[0] for r in chk.rows}
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(psa_type=1, compact=False, shrink_factor=1, mask_h=17, mask_w=17, normalization_factor=None, psa_softmax=False),
+    dict(psa_type=2, compact=True, shrink_factor=2, mask_h=5, mask_w=5, normalization_factor=1.0, psa_softmax=True),
+])
+def test_insitu_psanet_variants(cfg, report):
+    _case(report, "psanet50 %s" % (cfg,), "psa", 50, 19, 65, 2, psa_cfg=cfg, oracle_loss=False)
+
+
+@pytest.mark.skipif(os.environ.get("SEMSEG_SKIP_BIG_INSITU") == "1", reason="big in-situ cases disabled")
+def test_insitu_pspnet101_473(report):
+    """The metric model at the metric resolution (per-GPU batch 2)."""
+    chk = _case(report, "pspnet101 c150 473^2 b2", "psp", 101, 150, 473, 2)
+    assert sum(1 for r in chk.rows if r[0] == "conv" and r[2] == "wgrad") == 113   # every MFMA conv of the net
+
+
+@pytest.mark.skipif(os.environ.get("SEMSEG_SKIP_BIG_INSITU") == "1", reason="big in-situ cases disabled")
+def test_insitu_psanet101_465(report):
+    """BASELINE configs[3]: PSANet-101 465x465, 150 classes, full 59x59 mask, batch 2."""
+    cfg = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=59, mask_w=59, normalization_factor=1.0,
+               psa_softmax=True)
+    _case(report, "psanet101 c150 465^2 b2 mask59", "psa", 101, 150, 465, 2, psa_cfg=cfg)

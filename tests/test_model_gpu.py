@@ -286,6 +286,41 @@ def test_all_pixels_ignored_gives_nan_like_torch(report):
     report("all-ignored batch -> NaN losses (torch semantics)")
 
 
+def test_all_pixels_ignored_backward_is_zero_like_torch(report):
+    """with no valid pixel torch's nll_loss backward leaves grad_input at 0 (only the loss is NaN), so
+    the gradients of an all-ignored shard are finite zeros and the other ranks' SGD step survives.  Checked on
+    the fused head's backward directly (scale = gmul / count must not become inf * 0 = NaN)."""
+    from semseg_amd import ops
+    N, h, w, H, W, C = 2, 6, 6, 41, 41, 5
+    scores = torch.randn(N, h, w, 128, device="cuda")
+    label = torch.full((N, H, W), 255, dtype=torch.int64, device="cuda")
+    lse = torch.empty(N, H, W, device="cuda")
+    acc = torch.zeros(2, dtype=torch.float64, device="cuda")
+    loss = torch.empty(1, device="cuda")
+    ops.ce_head_fwd(scores, 128, label, lse, None, acc, loss, N, h, w, H, W, C, 255)
+    assert torch.isnan(loss).item()
+    gl = torch.ones(1, device="cuda")
+    for scratch in (None, torch.empty(1 << 20, device="cuda")):      # gather form and cell form
+        dz = torch.full((N, h, w, 128), 7.0, device="cuda")
+        ops.ce_head_bwd(scores, 128, label, lse, acc, gl, 1.0, dz, 128, False, N, h, w, H, W, C, 255, scratch=scratch)
+        assert torch.isfinite(dz[..., :C]).all().item() and float(dz[..., :C].abs().max()) == 0.0
+    report("all-ignored batch -> zero (finite) score gradients in both CE backward forms")
+
+
+def test_out_of_range_labels_raise_like_torch(report):
+    """a class id outside [0, C) that is not ignore_index raises (torch: 'Target out of bounds')."""
+    from model.pspnet import PSPNet
+    m = PSPNet(layers=50, classes=5, zoom_factor=8, dropout=0.0, pretrained=False).cuda().train()
+    x = torch.randn(2, 3, 41, 41).cuda()
+    y = torch.randint(0, 5, (2, 41, 41)).cuda()
+    y[0, 3, 4] = 5
+    with pytest.raises(IndexError):
+        m(x, y)
+    y[0, 3, 4] = 255
+    m(x, y)
+    report("out-of-range label raises IndexError; ignore_index passes")
+
+
 def test_argument_checks():
     """The reference's assertions (model/pspnet.py:32-35,82)."""
     from model.pspnet import PSPNet
