@@ -1,13 +1,15 @@
 """`PSAMask` autograd Function — same contract as the reference's lib/psa/functions/psamask.py:6-39
-(argument checks, zero-filled [N, H*W, H, W] output, adjoint backward), with the native call routed to
-the gfx950 kernels through the C ABI (semseg_psamask_forward/backward, include/semseg_hip.h) on the
-*current* stream.  fp32 CUDA tensors only; anything else raises (the reference would read garbage
-through `.data<float>()`; there is deliberately no CPU path here).
+(argument checks, zero-filled [N, H*W, H, W] output, adjoint backward).  The native call is the reference's own:
+`src.gpu.psamask_forward(psa_type, input, output, num_, feature_H_, feature_W_, mask_H_, mask_W_, half_mask_H_,
+half_mask_W_)` (psamask.py:20,35) on the pybind module `psamask_gpu` (lib/psa/src/gpu/operator.cpp), which forwards
+to the gfx950 kernels through the C ABI (semseg_psamask_forward/backward, include/semseg_hip.h) on the *current*
+stream.  fp32 CUDA tensors only; anything else raises (the reference would read garbage through `.data<float>()`;
+there is deliberately no CPU path here).
 """
 import torch
 from torch.autograd import Function
 
-from semseg_amd import ops
+from .. import src
 
 
 def _check(t, what):
@@ -36,7 +38,7 @@ class PSAMask(Function):
         n, chans, fh, fw, mh, mw, hh, hw = geo
         _check(input, "input")
         output = torch.zeros((n, fh * fw, fh, fw), dtype=input.dtype, device=input.device)
-        ops.psamask_forward(psa_type, input.contiguous(), output, n, fh, fw, mh, mw, hh, hw)
+        src.gpu.psamask_forward(psa_type, input.contiguous(), output, n, fh, fw, mh, mw, hh, hw)
         ctx.cfg = (psa_type,) + geo
         return output
 
@@ -47,7 +49,7 @@ class PSAMask(Function):
         # the reference assumes a dense gradient (a stride-0 grad makes it read garbage)
         grad_output = grad_output.contiguous()
         grad_input = torch.zeros((n, chans, fh, fw), dtype=grad_output.dtype, device=grad_output.device)
-        ops.psamask_backward(psa_type, grad_output, grad_input, n, fh, fw, mh, mw, hh, hw)
+        src.gpu.psamask_backward(psa_type, grad_output, grad_input, n, fh, fw, mh, mw, hh, hw)
         return grad_input, None, None, None
 
 
