@@ -107,3 +107,83 @@ def test_poly_lr_matches_reference_formula():
     # util/util.py:34-37: base_lr * (1 - curr_iter / max_iter) ** power
     assert poly_learning_rate(0.01, 0, 100) == pytest.approx(0.01)
     assert poly_learning_rate(0.01, 50, 100, 0.9) == pytest.approx(0.01 * 0.5 ** 0.9)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: multi-scale test path sharded over crops (semseg_amd/infer.py) — work plan + reduce
+# ---------------------------------------------------------------------------------------------------------------
+def _tester(cls=None):
+    from semseg_amd.infer import MultiScaleTester
+    cls = cls or MultiScaleTester
+    t = cls.__new__(cls)
+    t.classes, t.base_size, t.crop_h, t.crop_w = 5, 512, 473, 473
+    t.scales, t.stride_rate, t.max_batch_crops = (0.5, 0.75, 1.0, 1.25, 1.5, 1.75), 2.0 / 3.0, 16
+    t.shard, t.group, t.all_ranks = True, None, False
+    t.device = torch.device("cpu")
+    return t
+
+
+def test_crop_shards_partition_the_units():
+    """512x512 image, six ADE scales -> 1+1+4+4+4+9 = 23 crops (46 forwards); every world size
+    gets each (scale, crop) exactly once, shard sizes differ by at most one."""
+    t = _tester()
+    plan = t.plan(512, 512)
+    assert [len(s["pos"]) for s in plan] == [1, 1, 4, 4, 4, 9] and t.num_forwards(512, 512) == 46
+    for world in (1, 2, 3, 4, 8, 23, 32):
+        seen, sizes = [], []
+        for r in range(world):
+            mine = t.shard_units(plan, r, world)
+            sizes.append(sum(len(v) for v in mine.values()))
+            seen += [(si, ci) for si, cs in mine.items() for ci in cs]
+        assert sorted(seen) == [(si, ci) for si, s in enumerate(plan) for ci in range(len(s["pos"]))]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _infer_worker(rank, world, port, q):
+    """The real predict() control flow (plan -> shard -> per-scale accumulation -> ONE reduce -> argmax on rank 0)
+    with the device kernels replaced by a deterministic CPU stand-in per (scale, crop)."""
+    from semseg_amd.infer import MultiScaleTester
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Stub(MultiScaleTester):
+        calls = 0
+
+        def _accumulate_scale(self, img, h, w, sc, crops, total, sharded):
+            for ci in crops:
+                g = torch.Generator().manual_seed(1000 * int(sc["sh"]) + ci)
+                total += torch.rand(total.shape, generator=g) / len(self.scales)
+                Stub.calls += 1
+
+        def _argmax(self, total, C, h, w):
+            return total.argmax(0)
+    try:
+        t = _tester(Stub)
+        out = t.predict(torch.zeros(40, 48, 3).numpy(), return_prob=True)
+        q.put((rank, Stub.calls, None if out[0] is None else (out[0].numpy().copy(), out[1].numpy().copy())))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_sharded_multi_scale_predict_world2_equals_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_infer_worker, args=(0, 1, 0, q))
+    p.start()
+    _, calls1, one = q.get(timeout=120)
+    p.join(60)
+    port = _free_port()
+    ps = [ctx.Process(target=_infer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+    assert res[0][1] + res[1][1] == calls1 and abs(res[0][1] - res[1][1]) <= 1     # every crop once, balanced
+    assert res[1][2] is None                                                       # only rank 0 gets the result
+    pred2, prob2 = res[0][2]
+    import numpy as np
+    assert np.allclose(prob2, one[1], atol=1e-5) and float((pred2 == one[0]).mean()) > 0.999

@@ -51,3 +51,34 @@ def test_multi_scale_pipeline_vs_oracle(hw, scales, report):
     report("multi-scale test pipeline %s scales %s: prob max-abs err %.2e argmax agreement %.5f (%d forwards)"
            % (hw, scales, e, agree, t.num_forwards(*hw)))
     assert e < 2e-4 and agree > 0.998
+
+
+def test_sharded_multi_scale_two_ranks(report):
+    """BASELINE.json configs[4] / SURVEY.md section 8e "Test path": the crops of all scales sharded over 2 ranks + ONE
+    reduce of the [C,h,w] probability sum reproduce the single-process result (fp32 summation order differs)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tmp = tempfile.mkdtemp(prefix="semseg_infer_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(root, "tests", "infer_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    subprocess.check_call([sys.executable, worker, tmp], env=env, timeout=600)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), worker, tmp], env=env, timeout=900)
+    one = np.load(os.path.join(tmp, "infer_rank0_of1.npz"))
+    r0 = np.load(os.path.join(tmp, "infer_rank0_of2.npz"))
+    r1 = np.load(os.path.join(tmp, "infer_rank1_of2.npz"))
+    assert r1["pred"].size == 0 and int(r0["ncrops"]) + int(r1["ncrops"]) == int(one["ncrops"])
+    assert abs(int(r0["ncrops"]) - int(r1["ncrops"])) <= 1
+    e = float(np.abs(r0["prob"] - one["prob"]).max())
+    agree = float((r0["pred"] == one["pred"]).mean())
+    report("crop-sharded multi-scale test, 2 ranks (%d + %d crops) vs 1: prob max-abs diff %.2e, argmax agreement %.5f"
+           % (int(r0["ncrops"]), int(r1["ncrops"]), e, agree))
+    assert e < 2e-6 and agree > 0.9999
