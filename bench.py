@@ -26,7 +26,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f
 
 
 def conv_flops_per_image(model, size):
-    """Algorithmic conv FLOPs (2*MAC) of one forward, per image (477.4 GF for PSPNet101)."""
+    """Algorithmic conv (+ PSA bmm) FLOPs (2*MAC) of one forward, per image (477.4 GF for
+    PSPNet101 @473, 487.2 + 1.66 GF for PSANet101 @465)."""
     from semseg_amd.ops import conv_out
     import torch.nn as nn
     # spatial size seen by each conv: replay the stride structure of the trunk
@@ -51,10 +52,22 @@ def conv_flops_per_image(model, size):
                 hw[blk.downsample[0]] = (cur, out)
             cur = out
     feat = cur
+    bmm = 0.0
+    if hasattr(model, "psa") and getattr(model, "use_psa", True):
+        # PSA head (model/psanet.py:53-98): reduce convs on the trunk map, attention convs and proj on the shrunk map,
+        # plus the point-affinity contraction torch.bmm(x [C, hw], y [hw, hw]) per branch (psanet.py:90-91)
+        psa = model.psa
+        sf = psa.shrink_factor
+        small = (feat - 1) // sf + 1 if sf != 1 else feat
+        for name, m in psa.named_modules():
+            if isinstance(m, nn.Conv2d):
+                hw[m] = (feat, feat) if name.startswith("reduce") else (small, small)
+        nb = 2 if psa.psa_type == 2 else 1
+        bmm = nb * 2.0 * (small * small) ** 2 * psa.reduce[0].weight.shape[0]
     for m in model.modules():
         if isinstance(m, nn.Conv2d) and m not in hw:
             hw[m] = (feat, feat)
-    if hasattr(model, "ppm"):
+    if hasattr(model, "ppm") and getattr(model, "use_ppm", True):
         for f in model.ppm.features:
             b = f[0].output_size
             b = b if isinstance(b, int) else b[0]
@@ -62,6 +75,7 @@ def conv_flops_per_image(model, size):
     for m, (_, o) in hw.items():
         co, ci, r, s_ = m.weight.shape
         total += 2.0 * o * o * co * ci * r * s_
+    total += bmm
     first = 2.0 * s0 * s0 * 64 * 3 * 9
     return total, first
 
@@ -78,7 +92,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(layers, classes, size, iters=2):
+def cpu_baseline(layers, classes, size, iters=2, arch="psp"):
     """The reference's arithmetic on the host cores: oracle/segnet.py (bit-identical to the imported
     reference, see tests/golden/make_golden.py) forward + backward + SGD, batch 2."""
     from oracle import segnet
@@ -86,7 +100,15 @@ def cpu_baseline(layers, classes, size, iters=2):
     torch.manual_seed(0)
     cores = usable_cores()
     torch.set_num_threads(cores)
-    m = PSPNet(layers=layers, classes=classes, zoom_factor=8, pretrained=False)
+    psa_cfg = None
+    if arch == "psp":
+        m = PSPNet(layers=layers, classes=classes, zoom_factor=8, pretrained=False)
+    else:
+        from model.psanet import PSANet
+        m = PSANet(layers=layers, classes=classes, zoom_factor=8, pretrained=False)
+        psa_cfg = dict(psa_type=m.psa.psa_type, compact=m.psa.compact, shrink_factor=m.psa.shrink_factor,
+                       mask_h=m.psa.mask_h, mask_w=m.psa.mask_w, normalization_factor=m.psa.normalization_factor,
+                       psa_softmax=m.psa.psa_softmax)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
     opt = torch.optim.SGD(list(params.values()), lr=0.01, momentum=0.9, weight_decay=1e-4)
@@ -96,7 +118,7 @@ def cpu_baseline(layers, classes, size, iters=2):
     times = []
     for it in range(iters + 1):
         t0 = time.time()
-        _, ml, al = segnet.forward(sd, x, layers, "psp", training=True, y=y)
+        _, ml, al = segnet.forward(sd, x, layers, arch, training=True, y=y, psa_cfg=psa_cfg)
         loss = ml + 0.4 * al
         opt.zero_grad()
         loss.backward()
@@ -107,8 +129,9 @@ def cpu_baseline(layers, classes, size, iters=2):
     iters = len(times) - 1
     t = sum(times[1:]) / iters
     return {"value": round(B / t, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "PSPNet%d %dx%d train step (fwd+bwd+SGD) batch %d, %d timed iterations after 1 warm-up, "
-                      "torch CPU fp32 via oracle/segnet.py" % (layers, size, size, B, iters)}
+            "sample": "PS%sNet%d %dx%d train step (fwd+bwd+SGD) batch %d, %d timed iterations after 1 warm-up, "
+                      "torch CPU fp32 via oracle/segnet.py" % ("P" if arch == "psp" else "A", layers, size, size, B,
+                                                               iters)}
 
 
 def main():
@@ -150,7 +173,7 @@ def main():
     else:
         from model.psanet import PSANet
         model = PSANet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
-    fwd_flops, first_flops = conv_flops_per_image(model, args.size) if args.arch == "psp" else (0.0, 0.0)
+    fwd_flops, first_flops = conv_flops_per_image(model, args.size)
     model = model.to(dev).train()
     tr = Trainer(model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, aux_weight=0.4, sync_bn=True)
 
@@ -225,7 +248,7 @@ def main():
             out["roofline"] = roof
             out["kernel_families"] = kt.summary()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.layers, args.classes, args.size)
+            out["cpu_baseline"] = cpu_baseline(args.layers, args.classes, args.size, arch=args.arch)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1 or force_dist:

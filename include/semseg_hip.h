@@ -75,6 +75,16 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
                       hipStream_t stream);
 size_t semseg_conv_wgrad_scratch_floats(int Ci, int Co, int R, int S);
 
+/* Batched GEMMs on the same two matrix-core kernels (one launch, blockIdx.y = batch item; strides in floats) — the
+ * PSA point-affinity contraction torch.bmm(x, y) of model/psanet.py:90-91 and its two gradients:
+ *   rows:   C[b][M][Nout] = A[b][M][K] * Bt[b][Nout_pad][K]^T   (K % 32 == 0; Bt rows >= Nout readable, zero)
+ *   kmajor: out[b][Co][Ci] (=|+=) sum_k y[b][k][co] * x[b][k][ci]  (Ci % 64 == 0; scratch holds batch slab sets) */
+int semseg_gemm_rows_batched(const float* a, int lda, long long a_bs, const float* bt, long long bt_bs, float* c,
+                             int ldc, long long c_bs, int M, int K, int Nout, int batch, hipStream_t stream);
+int semseg_gemm_kmajor_batched(const float* x, int ldx, long long x_bs, const float* y, int ldy, long long y_bs,
+                               float* out, long long out_bs, float* scratch, size_t scratch_floats, int K, int Ci,
+                               int Co, int accumulate, int batch, hipStream_t stream);
+
 /* Stem conv 3->64, 3x3 stride 2 pad 1, reading the caller's NCHW input (model/resnet.py:108). */
 int semseg_stem_conv_fwd(const float* x_nchw, const float* w_oihw, float* y_nhwc, int N, int H,
                          int W, int Co, hipStream_t stream);

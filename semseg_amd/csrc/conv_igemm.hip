@@ -100,6 +100,10 @@ struct ConvArgs {
   float* part;        // partial slabs [ksplit][M - tail_m0][ldpart]
   int ldpart, tail_m0;
   FastDiv div_hw, div_w, div_tn, div_ks;  // Hout*Wout, Wout, tiles_n, ksplit
+  // Batched GEMM use (PSA point-affinity contraction, model/psanet.py:90-91): blockIdx.y = batch item, every
+  // operand advances by its batch stride (floats).  batch == 1: plain convolution.
+  int batch;
+  long long x_bs, w_bs, y_bs, add_bs;
 };
 
 // RS_T == 0: generic tap walk with global loads.  RS_T == 1 / 9 (1x1 / 3x3): the tap loop is unrolled
@@ -107,7 +111,15 @@ struct ConvArgs {
 // carry an out-of-range offset, which the buffer unit returns as 0) plus one scalar offset per K-step —
 // no per-K-step address VALU between the MFMAs at all.
 template <int BM, int BN, bool TR, int RS_T, bool TL>
-__global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OCC) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OCC) void conv_igemm_kernel(const ConvArgs pin) {
+  ConvArgs p = pin;
+  if (p.batch > 1) {
+    const long long bz = blockIdx.y;
+    p.x += bz * p.x_bs;
+    p.w += bz * p.w_bs;
+    p.y += bz * p.y_bs;
+    if (p.add) p.add += bz * p.add_bs;
+  }
   // BM/64 x 2 waves, each a 64 x (BN/2) sub-tile of 32x32 MFMA blocks
   constexpr int NT = BM * 2;                 // threads
   constexpr int RSTEP = NT / 8;              // tile rows staged per pass (8 lanes x 16 B per row)
@@ -662,13 +674,23 @@ struct WgradArgs {
   int ksplit, kper;  // kper: pixels per split (multiple of 32)
   int tiles_co, tiles_ci;
   FastDiv div_hw, div_wo;
+  // batched K-major GEMM (blockIdx.y = batch item): operand / slab strides in floats
+  int batch;
+  long long x_bs, dy_bs, dw_bs;
 };
 
 // MODE 0: generic gather (any stride / padding).  MODE 1: 1x1, stride 1, pad 0 — the gathered row IS row m,
 // no decode, always valid.  MODE 2: stride 1 with Ho x Wo == Hin x Win ("same" 3x3, any dilation) — the
 // gathered row is m + tap offset (linear); the pixel is decoded only for the border test.
 template <int TM, int TN, int MODE>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
+  WgradArgs p = pin;
+  if (p.batch > 1) {
+    const long long bz = blockIdx.y;
+    p.x += bz * p.x_bs;
+    p.dy += bz * p.dy_bs;
+    p.dw += bz * p.dw_bs;
+  }
   constexpr int MREP = TM / 64, NREP = TN / 64;
   constexpr int YV = TM / 4, XV = TN / 4;          // float4 per k-row
   constexpr int Y_PER = 32 * YV / 256, X_PER = 32 * XV / 256;
@@ -829,12 +851,190 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient, direct-to-LDS variant (128 x 128 tiles).  Both operands are K-major in memory exactly as the
+// MFMA wants them in LDS ([k][row], a k-row of 128 floats = 512 contiguous bytes of one pixel), so a tile is a
+// lane-linear image: every wave streams its k-rows with `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB per
+// wave-instruction) into an NSTAGE-deep LDS ring — no staging VGPRs, no ds_write pass, and the prefetch depth is
+// set by the ring, not by registers.  Invalid rows (padding taps, rows past M) carry an out-of-range buffer offset:
+// the buffer unit returns 0 for them, which is what lands in LDS.  One raw s_barrier per K-step; the DMA queue is
+// drained with a COUNTED vmcnt so that NSTAGE-2 stages stay in flight across the barrier.
+// Fragments are read as ds_read_b64: lane l31 takes tile rows (2*l31, 2*l31+1), i.e. MFMA block i holds the rows
+// 2*r + i — a relabelling that only the epilogue sees (and which turns its stores into 8-byte lanes).
+// ------------------------------------------------------------------------------------------
+template <int MODE, int KS, int NSTAGE, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArgs pin) {
+  WgradArgs p = pin;
+  if (p.batch > 1) {
+    const long long bz = blockIdx.y;
+    p.x += bz * p.x_bs;
+    p.dy += bz * p.dy_bs;
+    p.dw += bz * p.dw_bs;
+  }
+  constexpr int TM = 128, TN = 128;
+  constexpr int STAGE_F = KS * (TM + TN);
+  constexpr int RPW = KS / 4;   // k-rows each wave streams per operand per stage
+  constexpr int NI = RPW / 2;   // DMA instructions per operand per wave per stage (2 k-rows = 1 KiB each)
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_F];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int RS = p.R * p.S;
+#if WGRAD_XCD
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+#else
+  int b = blockIdx.x;
+#endif
+  const int tci = b % p.tiles_ci; b /= p.tiles_ci;
+  const int tco = b % p.tiles_co; b /= p.tiles_co;
+  const int tap = b % RS;
+  const int ks = b / RS;
+  const int r = tap / p.S, s = tap - r * p.S;
+  const int co0 = tco * TM, ci0 = tci * TN;
+  const int kbeg = ks * p.kper;
+  const int kend = min(p.M, kbeg + p.kper);
+  const int hw = p.Ho * p.Wo;
+
+  // raw buffers: rows past the end of dy / x are out of range by construction (num_records), so the M tail needs
+  // no test at all for dy and for the 1x1 case
+  const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.dy, 0, (int)min((size_t)0x7FFFFFFFu, (size_t)p.M * p.lddy * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.x, 0, (int)min((size_t)0x7FFFFFFFu, (size_t)p.N * p.Hin * p.Win * p.ldx * 4), 0x00020000);
+
+  // this lane's k-row inside a stage, per DMA instruction, and its 16-byte column
+  const int rrow = wave * RPW + lhi;   // + 2*i
+  const int col = l31 * 4;
+  unsigned yoff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) yoff[i] = (unsigned)(((kbeg + rrow + 2 * i) * p.lddy + co0 + col) * 4);
+  const unsigned ystep = (unsigned)(KS * p.lddy * 4);
+  // x: byte offset of (row m, this lane's column) is m * ldx * 4 + xcol (+ the tap shift in the linear modes)
+  const int tapoff = ((r * p.dil - p.pad) * p.Win + (s * p.dil - p.pad)) * p.ldx + ci0 + col;
+  unsigned xoff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) xoff[i] = (unsigned)(((kbeg + rrow + 2 * i) * p.ldx + tapoff) * 4);
+  const unsigned xstep = (unsigned)(KS * p.ldx * 4);
+
+  auto issue = [&](int kb, int slot) {
+    float* Ysl = smem + slot * STAGE_F;
+    float* Xsl = Ysl + KS * TM;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ry_, Ysl + (wave * RPW + 2 * i) * TM, 16, yoff[i], 0, 0, 0);
+      yoff[i] += ystep;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      unsigned vo;
+      if constexpr (MODE == 1) {
+        vo = xoff[i];
+      } else {
+        const int m = kb + rrow + 2 * i;
+        const int mm = m < kend ? m : kbeg;
+        const int n = fdiv(mm, p.div_hw);
+        const int rem = mm - n * hw;
+        const int oh = fdiv(rem, p.div_wo);
+        const int ow = rem - oh * p.Wo;
+        const int ih = oh * p.stride + r * p.dil - p.pad;
+        const int iw = ow * p.stride + s * p.dil - p.pad;
+        const bool ok = m < kend && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        if constexpr (MODE == 2)
+          vo = ok ? xoff[i] : OOB;
+        else
+          vo = ok ? (unsigned)((((n * p.Hin + ih) * p.Win + iw) * p.ldx + ci0 + col) * 4) : OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, Xsl + (wave * RPW + 2 * i) * TN, 16, vo, 0, 0, 0);
+      xoff[i] += xstep;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 fa[2], fb[2];
+  // the first fragments of a stage are requested BEFORE the next stage's DMA is issued, so their LDS latency
+  // hides under that issue code instead of sitting between the barrier and the first MFMA
+  auto first_frags = [&](int slot) {
+    const float* Ya = smem + slot * STAGE_F + lhi * TM + wm * 64 + 2 * l31;
+    const float* Xa = smem + slot * STAGE_F + KS * TM + lhi * TN + wn * 64 + 2 * l31;
+    fa[0] = *reinterpret_cast<const f32x2*>(Ya);
+    fb[0] = *reinterpret_cast<const f32x2*>(Xa);
+  };
+  auto compute = [&](int slot) {
+    const float* Ya = smem + slot * STAGE_F + lhi * TM + wm * 64 + 2 * l31;
+    const float* Xa = smem + slot * STAGE_F + KS * TM + lhi * TN + wn * 64 + 2 * l31;
+#pragma unroll
+    for (int kp = 0; kp < KS / 2; ++kp) {
+      if (kp + 1 < KS / 2) {
+        fa[(kp + 1) & 1] = *reinterpret_cast<const f32x2*>(Ya + 2 * (kp + 1) * TM);
+        fb[(kp + 1) & 1] = *reinterpret_cast<const f32x2*>(Xa + 2 * (kp + 1) * TN);
+      }
+      const f32x2 a = fa[kp & 1], bb = fb[kp & 1];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bb[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bb[1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bb[0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bb[1], acc[1][1], 0, 0, 0);
+    }
+    // pin the issue order "fragments of k-pair kp+1, then the 4 MFMAs of k-pair kp" (the scheduler otherwise
+    // batches the reads of two k-pairs and waits for them right in front of 8 MFMAs)
+#pragma unroll
+    for (int kp = 0; kp < KS / 2; ++kp) {
+      if (kp + 1 < KS / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  };
+
+  const int nsteps = (kend - kbeg + KS - 1) / KS;
+  // Stages past the end of this split are issued too (their rows are either another split's valid memory or out
+  // of range): the DMA count per iteration stays constant, which is what the counted vmcnt relies on.
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) issue(kbeg + st * KS, st);
+  int slot = 0, pslot = NSTAGE - 1;
+  for (int t = 0; t < nsteps; ++t) {
+    // stage t has landed for this wave once at most NSTAGE-2 younger stages are still outstanding ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI * (NSTAGE - 2)) : "memory");
+    // ... and for every wave after the barrier, which also says: everybody is done reading slot (t-1) % NSTAGE
+    __builtin_amdgcn_s_barrier();
+    first_frags(slot);
+    issue(kbeg + (t + NSTAGE - 1) * KS, pslot);
+    compute(slot);
+    pslot = slot;
+    slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the workgroup has retired
+
+  float* out = p.dw + (size_t)ks * p.Co_pad * RS * p.Ci;
+  const int ci = ci0 + wn * 64 + 2 * l31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rr = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      const int co = co0 + wm * 64 + 2 * rr + i;
+      f32x2 v = {acc[i][0][e], acc[i][1][e]};
+      *reinterpret_cast<f32x2*>(out + ((size_t)co * RS + tap) * p.Ci + ci) = v;
+    }
+}
+
 // dW partial slabs [ksplit][Co_pad][RS][Ci] -> OIHW gradient [Co][Ci][R][S] (sum over ksplit).
 __global__ void wgrad_reduce_unpack_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                            int ksplit, int Co, int Co_pad, int Ci, int RS,
-                                           int accumulate) {
+                                           int accumulate, long long part_bs, long long dw_bs) {
   const size_t total = (size_t)Co * Ci * RS;
   const size_t slab = (size_t)Co_pad * RS * Ci;
+  part += (size_t)blockIdx.y * part_bs;   // batched K-major GEMM: blockIdx.y = batch item
+  dw += (size_t)blockIdx.y * dw_bs;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
     const int tap = (int)(idx % RS);
@@ -970,6 +1170,7 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   const int BMr = big ? 256 : 128;
   const int tiles_m = (a.M + BMr - 1) / BMr;
   ConvArgs p = a;
+  if (p.batch > 1) { scratch = nullptr; scratch_floats = 0; }   // batched GEMM: the batch fills the chip, no split-K
   p.tiles_n = (a.Nout + BN - 1) / BN;
   const int tiles = tiles_m * p.tiles_n;
   const int KT = a.R * a.S * (a.Kc / BK);
@@ -1028,7 +1229,8 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   const bool bl = CONV_BUFLOAD && !big && (RSv == 1 || RSv == 9) && (p.kt_per % RSv == 0) &&
                   x_bytes < 0x7FFF0000ull && w_bytes < 0x7FFF0000ull;
   const bool tl = BN == 128 && KT >= 128;      // two-level accumulation for K >= 4096 (see the kernel)
-#define LAUNCH_CONV_(BM_, BN_, TR_, RS_, TL_) conv_igemm_kernel<BM_, BN_, TR_, RS_, TL_><<<grid, BM_ * 2, 0, stream>>>(p)
+#define LAUNCH_CONV_(BM_, BN_, TR_, RS_, TL_) \
+  conv_igemm_kernel<BM_, BN_, TR_, RS_, TL_><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p)
 #define LAUNCH_CONV(BM_, BN_, TR_, RS_)                                        \
   do {                                                                         \
     if (BN_ == 128 && tl) LAUNCH_CONV_(BM_, BN_, TR_, RS_, (BN_ == 128));      \
@@ -1084,6 +1286,7 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
   a.N = N; a.Hin = H; a.Win = W; a.Hout = Ho; a.Wout = Wo;
   a.Kc = Ci; a.Nout = Co; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * Ho * Wo; a.tiles_n = 0; a.stats_nslot = stats_nslot > 0 ? stats_nslot : 1;
+  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0;
   return conv_launch(false, a, tile_n, scratch, scratch_floats, stream);
 }
 
@@ -1100,14 +1303,15 @@ int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx
   a.N = N; a.Hin = Ho; a.Win = Wo; a.Hout = H; a.Wout = W;
   a.Kc = Kc; a.Nout = Ci; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * H * W; a.tiles_n = 0; a.stats_nslot = 1;
+  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0;
   return conv_launch(true, a, tile_n, scratch, scratch_floats, stream);
 }
 
-int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
-                      float* scratch, size_t scratch_floats, int N, int H, int W, int Ci, int Ho,
-                      int Wo, int Co, int R, int S, int stride, int pad, int dil, int accumulate,
-                      hipStream_t stream) {
-  if (!x || !dy || !dw_oihw || !scratch || (ldx & 3) || (lddy & 3) || Ci % 64 != 0)
+static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
+                        float* scratch, size_t scratch_floats, int N, int H, int W, int Ci, int Ho,
+                        int Wo, int Co, int R, int S, int stride, int pad, int dil, int accumulate,
+                        int batch, long long x_bs, long long dy_bs, long long out_bs, hipStream_t stream) {
+  if (!x || !dy || !dw_oihw || !scratch || (ldx & 3) || (lddy & 3) || Ci % 64 != 0 || batch < 1)
     return SEMSEG_EINVAL;
   const int RS = R * S;
   const int M = N * Ho * Wo;
@@ -1119,7 +1323,9 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
   // 3x3 with 36 tiles -9 % at 7200, +2 % at 14400; cls.0 (1152 tiles) +10...18 % everywhere.
   const int t128 = ((Co + 127) / 128) * (Ci / 128) * RS;
   const bool small_tiles = (RS == 1 && t128 <= 16 && M < 32768) || (RS > 1 && t128 <= 36 && M < 8192);
-  const bool big = (Ci % 128 == 0) && (Co >= 128) && !(WGRAD_SMALL_TILES && small_tiles);
+  const char* small_s = getenv("SEMSEG_WGRAD_SMALL");   // "0": never fall back to 64 x 64 tiles (tests / tuning)
+  const bool allow_small = WGRAD_SMALL_TILES && !(small_s && small_s[0] == '0');
+  const bool big = (Ci % 128 == 0) && (Co >= 128) && !(allow_small && small_tiles);
   const int TM = big ? 128 : 64, TN = big ? 128 : 64;
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = scratch; a.ldx = ldx; a.lddy = lddy;
@@ -1133,16 +1339,28 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
   a.div_wo = make_fastdiv(Wo);
   const int tiles = a.tiles_co * a.tiles_ci * RS;
   const int ksteps = (M + 31) / 32;
+  a.batch = batch; a.x_bs = x_bs; a.dy_bs = dy_bs;
+  scratch_floats /= batch;   // every batch item owns its own slab set
+  // Direct-to-LDS variant of the 128 x 128 kernel (SEMSEG_WGRAD_DMA = 1..5 picks K-step / ring depth / residency;
+  // 0 = register-staged kernel).  Needs byte offsets below 2^31 for both operands.
+#ifndef WGRAD_DMA_DEFAULT
+#define WGRAD_DMA_DEFAULT 0
+#endif
+  const char* dma_s = getenv("SEMSEG_WGRAD_DMA");   // read per call: scripts switch variants inside one process
+  const int dma_env = dma_s ? atoi(dma_s) : WGRAD_DMA_DEFAULT;
+  const bool dma_ok = (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
+  const int dma = (big && dma_ok) ? dma_env : 0;
+  static const int occ_of[6] = {3, 2, 3, 2, 5, 5};
   // aim at one full residency round (256 CUs x resident workgroups per CU) without spilling into a second
-  constexpr int ROUND = 768;
-  int ksplit = ROUND / tiles;
-  if (tiles > ROUND / 2) {
+  const int ROUND = 256 * occ_of[dma < 0 || dma > 5 ? 0 : dma];
+  int ksplit = ROUND / (tiles * batch);
+  if (tiles * batch > ROUND / 2) {
     // more than half a round of tiles already: pick the K split whose workgroup count fills whole
     // residency rounds best (e.g. cls.0: 1152 tiles -> x2 = 2304 = 3 rounds exactly)
     double best = 0.0;
     ksplit = 1;
     for (int ks = 1; ks <= 8; ++ks) {
-      const int wgs = tiles * ks;
+      const int wgs = tiles * batch * ks;
       const double eff = (double)wgs / (double)(((wgs + ROUND - 1) / ROUND) * ROUND);
       if (eff > best + 0.02) { best = eff; ksplit = ks; }
     }
@@ -1155,7 +1373,8 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
   a.kper = ((ksteps + ksplit - 1) / ksplit) * 32;
   ksplit = (M + a.kper - 1) / a.kper;
   a.ksplit = ksplit;
-  const int grid = tiles * ksplit;
+  a.dw_bs = (long long)(slab * ksplit);
+  const dim3 grid(tiles * ksplit, batch);
 #ifndef CONV_WGRAD_LINEAR
 #define CONV_WGRAD_LINEAR 1
 #endif
@@ -1167,12 +1386,57 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
     else if (mode == 2) conv_wgrad_kernel<TM_, TN_, 2><<<grid, 256, 0, stream>>>(a);  \
     else conv_wgrad_kernel<TM_, TN_, 0><<<grid, 256, 0, stream>>>(a);                 \
   } while (0)
-  if (big) LAUNCH_WGRAD(128, 128); else LAUNCH_WGRAD(64, 64);
+#define LAUNCH_WGRAD_DMA(KS_, NST_, OCC_)                                                          \
+  do {                                                                                             \
+    if (mode == 1) conv_wgrad_dma_kernel<1, KS_, NST_, OCC_><<<grid, 256, 0, stream>>>(a);         \
+    else if (mode == 2) conv_wgrad_dma_kernel<2, KS_, NST_, OCC_><<<grid, 256, 0, stream>>>(a);    \
+    else conv_wgrad_dma_kernel<0, KS_, NST_, OCC_><<<grid, 256, 0, stream>>>(a);                   \
+  } while (0)
+  if (big && dma == 1) LAUNCH_WGRAD_DMA(32, 2, 2);
+  else if (big && dma == 2) LAUNCH_WGRAD_DMA(16, 3, 3);
+  else if (big && dma == 3) LAUNCH_WGRAD_DMA(16, 4, 2);
+  else if (big && dma == 4) LAUNCH_WGRAD_DMA(16, 2, 4);
+  else if (big && dma == 5) LAUNCH_WGRAD_DMA(8, 4, 4);
+  else if (big) LAUNCH_WGRAD(128, 128); else LAUNCH_WGRAD(64, 64);
+#undef LAUNCH_WGRAD_DMA
 #undef LAUNCH_WGRAD
   const size_t total = (size_t)Co * Ci * RS;
-  wgrad_reduce_unpack_kernel<<<grid_for(total, 256), 256, 0, stream>>>(scratch, dw_oihw, ksplit, Co,
-                                                                      a.Co_pad, Ci, RS, accumulate);
+  wgrad_reduce_unpack_kernel<<<dim3(grid_for(total, 256), batch), 256, 0, stream>>>(
+      scratch, dw_oihw, ksplit, Co, a.Co_pad, Ci, RS, accumulate, a.dw_bs, out_bs);
   return semseg_launch_status();
+}
+
+int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
+                      float* scratch, size_t scratch_floats, int N, int H, int W, int Ci, int Ho,
+                      int Wo, int Co, int R, int S, int stride, int pad, int dil, int accumulate,
+                      hipStream_t stream) {
+  return wgrad_launch(x, ldx, dy, lddy, dw_oihw, scratch, scratch_floats, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad,
+                      dil, accumulate, 1, 0, 0, 0, stream);
+}
+
+// Batched GEMMs on the two matrix-core kernels — the PSA point-affinity contraction (torch.bmm at
+// model/psanet.py:90-91) and its two gradients as ONE launch each instead of a per-image loop.
+//   rows:   C[b][M][Nout] (+= add) = A[b][M][K] * Bt[b][Nout_pad][K]^T      (K % 32 == 0, Bt rows zero padded)
+//   kmajor: out[b][Co][Ci] (=|+=) sum_k y[b][k][co] * x[b][k][ci]           (Ci % 64 == 0)
+int semseg_gemm_rows_batched(const float* a, int lda, long long a_bs, const float* bt, long long bt_bs, float* c,
+                             int ldc, long long c_bs, int M, int K, int Nout, int batch, hipStream_t stream) {
+  if (!a || !bt || !c || K % 32 != 0 || (lda & 3) || batch < 1 || batch > 65535) return SEMSEG_EINVAL;
+  ConvArgs g;
+  g.x = a; g.w = bt; g.y = c; g.bias = nullptr; g.scale = nullptr; g.relu = 0; g.add = nullptr; g.stats = nullptr;
+  g.ldx = lda; g.ldy = ldc; g.ldadd = 0;
+  g.N = 1; g.Hin = M; g.Win = 1; g.Hout = M; g.Wout = 1;
+  g.Kc = K; g.Nout = Nout; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.dil = 1;
+  g.M = M; g.tiles_n = 0; g.stats_nslot = 1;
+  g.batch = batch; g.x_bs = a_bs; g.w_bs = bt_bs; g.y_bs = c_bs; g.add_bs = 0;
+  return conv_launch(false, g, Nout >= 128 ? 128 : 64, nullptr, 0, stream);
+}
+
+int semseg_gemm_kmajor_batched(const float* x, int ldx, long long x_bs, const float* y, int ldy, long long y_bs,
+                               float* out, long long out_bs, float* scratch, size_t scratch_floats, int K, int Ci,
+                               int Co, int accumulate, int batch, hipStream_t stream) {
+  if (batch > 65535) return SEMSEG_EINVAL;
+  return wgrad_launch(x, ldx, y, ldy, out, scratch, scratch_floats, 1, K, 1, Ci, K, 1, Co, 1, 1, 1, 0, 1, accumulate,
+                      batch, x_bs, y_bs, out_bs, stream);
 }
 
 size_t semseg_conv_wgrad_scratch_floats(int Ci, int Co, int R, int S) {

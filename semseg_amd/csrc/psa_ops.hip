@@ -13,51 +13,108 @@
 
 namespace {
 
-// type 0 (collect):    A[n,(h,w),(h',w')] = M[n,(h,w), (h'-h+hh)*mW + (w'-w+hw)]
-// type 1 (distribute): A[n,(h',w'),(h,w)] = M[n,(h,w), (h'-h+hh)*mW + (w'-w+hw)]
-__global__ __launch_bounds__(256) void psamask_nhwc_fwd_kernel(const float* __restrict__ m, int ldm,
-                                                               float* __restrict__ a, int lda,
-                                                               int type, int N, int H, int W, int mH,
-                                                               int mW, int hh, int hw) {
-  const int HW = H * W;
-  const size_t total = (size_t)N * HW * HW;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int p = (int)(i % HW);
-    size_t t = i / HW;
-    const int q = (int)(t % HW);
-    const int n = (int)(t / HW);
-    int h, w, hp, wp;  // (h,w): pixel that predicted the mask; (hp,wp): shifted position
-    if (type == 0) { h = q / W; w = q - h * W; hp = p / W; wp = p - hp * W; }
-    else { hp = q / W; wp = q - hp * W; h = p / W; w = p - h * W; }
-    const int hi = hp - h + hh, wi = wp - w + hw;
+// With a = the pixel that predicted the mask row and b = the shifted position it talks about,
+//     G[n, a, b] = M[n, a, (h_b - h_a + hh) * mW + (w_b - w_a + hw)]     (0 outside the mask window)
+// type 0 (collect) is A = G and type 1 (distribute) is A = G^T per image (lib/psa/src/cpu/psamask.cpp:26-29 vs
+// 52-55).  One workgroup owns a 64 x 64 tile of G: lanes run along b, so for a fixed a the 64 source taps are
+// runs of W contiguous floats of ONE mask row; the tile goes through LDS, which makes the store coalesced for both
+// types (rows of A along b for collect, along a for distribute).  32-bit index arithmetic only, the per-lane b is
+// decoded once per tile (the previous one-thread-per-element kernels spent their time in 64-bit div/mod).
+constexpr int PT = 64;   // tile edge
+
+struct PsaNhwcArgs {
+  const float* src;
+  float* dst;
+  int lds_, ldd, type, N, H, W, mH, mW, hh, hw, tiles;
+};
+
+__global__ __launch_bounds__(256) void psamask_nhwc_fwd_kernel(const PsaNhwcArgs p) {
+  __shared__ float tile[PT][PT + 1];
+  const int HW = p.H * p.W;
+  int blk = blockIdx.x;
+  const int tb = blk % p.tiles; blk /= p.tiles;
+  const int ta = blk % p.tiles;
+  const int n = blk / p.tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = tb * PT + lane;
+  const int hb = b / p.W, wb = b - hb * p.W;
+  const float* mrow = p.src + (size_t)n * HW * p.lds_;
+#pragma unroll 4
+  for (int r = wave; r < PT; r += 4) {
+    const int a = ta * PT + r;                      // wave-uniform
+    const int ha = a / p.W, wa = a - ha * p.W;
+    const int hi = hb - ha + p.hh, wi = wb - wa + p.hw;
     float v = 0.f;
-    if (hi >= 0 && hi < mH && wi >= 0 && wi < mW)
-      v = m[((size_t)n * HW + h * W + w) * ldm + hi * mW + wi];
-    a[((size_t)n * HW + q) * lda + p] = v;
+    if (a < HW && b < HW && (unsigned)hi < (unsigned)p.mH && (unsigned)wi < (unsigned)p.mW)
+      v = mrow[(size_t)a * p.lds_ + hi * p.mW + wi];
+    tile[r][lane] = v;
+  }
+  __syncthreads();
+  float* arow = p.dst + (size_t)n * HW * p.ldd;
+  if (p.type == 0) {
+#pragma unroll 4
+    for (int r = wave; r < PT; r += 4) {
+      const int a = ta * PT + r;
+      if (a < HW && b < HW) arow[(size_t)a * p.ldd + b] = tile[r][lane];
+    }
+  } else {
+    const int a = ta * PT + lane;
+#pragma unroll 4
+    for (int r = wave; r < PT; r += 4) {
+      const int bb = tb * PT + r;
+      if (a < HW && bb < HW) arow[(size_t)bb * p.ldd + a] = tile[lane][r];
+    }
   }
 }
 
-// dM[n,(h,w),(hi,wi)] = dA at the matching position, 0 when the shifted position is off the map
-__global__ __launch_bounds__(256) void psamask_nhwc_bwd_kernel(const float* __restrict__ da, int lda,
-                                                               float* __restrict__ dm, int ldm,
-                                                               int type, int N, int H, int W, int mH,
-                                                               int mW, int hh, int hw) {
-  const int HW = H * W, T = mH * mW;
-  const size_t total = (size_t)N * HW * T;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c = (int)(i % T);
-    size_t t = i / T;
-    const int pix = (int)(t % HW);
-    const int n = (int)(t / HW);
-    const int h = pix / W, w = pix - h * W;
-    const int hi = c / mW, wi = c - hi * mW;
-    const int hp = h + hi - hh, wp = w + wi - hw;
+// dM[n, a, (hi,wi)] = dG[n, a, b(a,hi,wi)], 0 when b is off the map; dG = dA (collect) or dA^T (distribute).
+// Collect: one workgroup per (n, a), lanes along the taps: reads are runs of <= W contiguous floats of row a of dA,
+// the store covers the whole tap row (zeros included) in order.
+__global__ __launch_bounds__(256) void psamask_nhwc_bwd_collect_kernel(const PsaNhwcArgs p) {
+  const int HW = p.H * p.W, T = p.mH * p.mW;
+  const int a = blockIdx.x % HW, n = blockIdx.x / HW;
+  const int ha = a / p.W, wa = a - ha * p.W;
+  const float* src = p.src + ((size_t)n * HW + a) * p.lds_;
+  float* dst = p.dst + ((size_t)n * HW + a) * p.ldd;
+  for (int c = threadIdx.x; c < T; c += 256) {
+    const int hi = c / p.mW, wi = c - hi * p.mW;
+    const int hb = ha + hi - p.hh, wb = wa + wi - p.hw;
     float v = 0.f;
-    if (hp >= 0 && hp < H && wp >= 0 && wp < W) {
-      const int sh = hp * W + wp;
-      v = (type == 0) ? da[((size_t)n * HW + pix) * lda + sh] : da[((size_t)n * HW + sh) * lda + pix];
+    if ((unsigned)hb < (unsigned)p.H && (unsigned)wb < (unsigned)p.W) v = src[hb * p.W + wb];
+    dst[c] = v;
+  }
+}
+
+// Distribute: the in-window taps of a 64 x 64 tile of dG = dA^T, staged through LDS so that the load runs along a
+// (rows of dA) and the store along b (runs of contiguous taps).  The caller zero-fills dM first (out-of-window taps).
+__global__ __launch_bounds__(256) void psamask_nhwc_bwd_distribute_kernel(const PsaNhwcArgs p) {
+  __shared__ float tile[PT][PT + 1];
+  const int HW = p.H * p.W;
+  int blk = blockIdx.x;
+  const int tb = blk % p.tiles; blk /= p.tiles;
+  const int ta = blk % p.tiles;
+  const int n = blk / p.tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* drow = p.src + (size_t)n * HW * p.lds_;
+  {
+    const int a = ta * PT + lane;
+#pragma unroll 4
+    for (int r = wave; r < PT; r += 4) {
+      const int bb = tb * PT + r;
+      tile[lane][r] = (a < HW && bb < HW) ? drow[(size_t)bb * p.lds_ + a] : 0.f;   // dG[a][b] = dA[b][a]
     }
-    dm[((size_t)n * HW + pix) * ldm + c] = v;
+  }
+  __syncthreads();
+  const int b = tb * PT + lane;
+  const int hb = b / p.W, wb = b - hb * p.W;
+  float* mrow = p.dst + (size_t)n * HW * p.ldd;
+#pragma unroll 4
+  for (int r = wave; r < PT; r += 4) {
+    const int a = ta * PT + r;
+    const int ha = a / p.W, wa = a - ha * p.W;
+    const int hi = hb - ha + p.hh, wi = wb - wa + p.hw;
+    if (a < HW && b < HW && (unsigned)hi < (unsigned)p.mH && (unsigned)wi < (unsigned)p.mW)
+      mrow[(size_t)a * p.ldd + hi * p.mW + wi] = tile[r][lane];
   }
 }
 
@@ -153,17 +210,29 @@ extern "C" {
 
 int semseg_psamask_nhwc_forward(int psa_type, const float* mask, int ldm, float* aff, int lda, int N,
                                 int H, int W, int mH, int mW, hipStream_t stream) {
-  if (!mask || !aff || lda < H * W || ldm < mH * mW) return SEMSEG_EINVAL;
-  psamask_nhwc_fwd_kernel<<<flat_grid((size_t)N * H * W * H * W), 256, 0, stream>>>(
-      mask, ldm, aff, lda, psa_type ? 1 : 0, N, H, W, mH, mW, (mH - 1) / 2, (mW - 1) / 2);
+  if (!mask || !aff || lda < H * W || ldm < mH * mW || N <= 0) return SEMSEG_EINVAL;
+  const int tiles = (H * W + PT - 1) / PT;
+  const long long grid = (long long)N * tiles * tiles;
+  if (grid > 2147483647LL) return SEMSEG_EINVAL;
+  PsaNhwcArgs a{mask, aff, ldm, lda, psa_type ? 1 : 0, N, H, W, mH, mW, (mH - 1) / 2, (mW - 1) / 2, tiles};
+  psamask_nhwc_fwd_kernel<<<(int)grid, 256, 0, stream>>>(a);
   return semseg_launch_status();
 }
 
 int semseg_psamask_nhwc_backward(int psa_type, const float* daff, int lda, float* dmask, int ldm,
                                  int N, int H, int W, int mH, int mW, hipStream_t stream) {
-  if (!daff || !dmask || lda < H * W || ldm < mH * mW) return SEMSEG_EINVAL;
-  psamask_nhwc_bwd_kernel<<<flat_grid((size_t)N * H * W * mH * mW), 256, 0, stream>>>(
-      daff, lda, dmask, ldm, psa_type ? 1 : 0, N, H, W, mH, mW, (mH - 1) / 2, (mW - 1) / 2);
+  if (!daff || !dmask || lda < H * W || ldm < mH * mW || N <= 0) return SEMSEG_EINVAL;
+  const int tiles = (H * W + PT - 1) / PT;
+  PsaNhwcArgs a{daff, dmask, lda, ldm, psa_type ? 1 : 0, N, H, W, mH, mW, (mH - 1) / 2, (mW - 1) / 2, tiles};
+  if (!psa_type) {
+    psamask_nhwc_bwd_collect_kernel<<<N * H * W, 256, 0, stream>>>(a);
+  } else {
+    // out-of-window taps are zero: clear the [N*H*W, ldm] block, then scatter the in-window tiles
+    if (hipMemsetAsync(dmask, 0, (size_t)N * H * W * ldm * sizeof(float), stream) != hipSuccess) return SEMSEG_ELAUNCH;
+    const long long grid = (long long)N * tiles * tiles;
+    if (grid > 2147483647LL) return SEMSEG_EINVAL;
+    psamask_nhwc_bwd_distribute_kernel<<<(int)grid, 256, 0, stream>>>(a);
+  }
   return semseg_launch_status();
 }
 

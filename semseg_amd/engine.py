@@ -148,6 +148,9 @@ class Engine:
         self.ktimer = None
         self._eval_epoch = 0
         self.side_wgrad = os.environ.get("SEMSEG_SIDE_WGRAD", "1") == "1"
+        # every weight gradient on the side stream (not only the small grids): the HBM-bound BatchNorm backward
+        # kernels of the main stream then share the chip with MFMA-bound work instead of running alone
+        self.side_all = os.environ.get("SEMSEG_SIDE_WGRAD_ALL", "0") == "1"
         self._side = None
         self._scr2 = None
         self._side_used = False
@@ -343,7 +346,7 @@ class Engine:
         # own (small per-GPU batch) it runs on a side HIP stream, concurrently with the data-gradient /
         # BatchNorm chain; both operands (x, dy) are final by now and stay untouched until the join at
         # the end of backward().
-        side = self.side_wgrad and y.M * cl.Co < 512 * 128 * 128
+        side = self.side_wgrad and (self.side_all or y.M * cl.Co < 512 * 128 * 128)
         if side:
             st = self._side_stream()
             st.wait_stream(torch.cuda.current_stream())
@@ -367,7 +370,7 @@ class Engine:
 
     def _scratch2(self):
         if self._scr2 is None:
-            self._scr2 = torch.empty(32 * 1024 * 1024, dtype=F32, device=self.device)
+            self._scr2 = torch.empty((64 if self.side_all else 32) * 1024 * 1024, dtype=F32, device=self.device)
         return self._scr2
 
     def scratch(self):

@@ -296,6 +296,23 @@ def gemm_kmajor(x_ptr, ldx, y_ptr, ldy, out_ptr, scratch, K, Ci, Co, accumulate=
                               K, 1, Co, 1, 1, 1, 0, 1, int(accumulate), _stream()), "gemm_kmajor")
 
 
+def gemm_rows_batched(a, lda, a_bs, bt, bt_bs, c, ldc, c_bs, M, K, Nout, batch):
+    """C[b][M][Nout] = A[b][M][K] * Bt[b][Nout_pad][K]^T in ONE launch (tensors or raw pointers; strides in floats)."""
+    _ck(lib.semseg_gemm_rows_batched(_ptr(a), lda, a_bs, _ptr(bt), bt_bs, _ptr(c), ldc, c_bs, M, K, Nout, batch,
+                                     _stream()), "gemm_rows_batched")
+
+
+def gemm_kmajor_batched(x, ldx, x_bs, y, ldy, y_bs, out, out_bs, scratch, K, Ci, Co, batch, accumulate=False):
+    """out[b][Co][Ci] (=|+=) sum_k y[b][k][co] * x[b][k][ci] in ONE launch of the weight-gradient kernel."""
+    _ck(lib.semseg_gemm_kmajor_batched(_ptr(x), ldx, x_bs, _ptr(y), ldy, y_bs, _ptr(out), out_bs, _p(scratch),
+                                       scratch.numel(), K, Ci, Co, int(accumulate), batch, _stream()),
+        "gemm_kmajor_batched")
+
+
+def _ptr(t):
+    return t if isinstance(t, int) else t.data_ptr()
+
+
 # ---------------------------------------------------------------------------------------------
 # test-time pipeline (tool/test.py:122-204) kept on the device
 # ---------------------------------------------------------------------------------------------

@@ -65,9 +65,11 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
     xT = eng.buf((N * C + PADROWS, P), zero=True, tag="psa_xT")
     ops.transpose_batched(xs.data, xs.ld, hw * xs.ld, xT, P, C * P, N, hw, C)
     zdst = zcat.slice(zoff, C)
-    for n in range(N):
-        ops.gemm_rows(aff[n * hw:].data_ptr(), P, xT[n * C:].data_ptr(), zdst.data[n].data_ptr(), zdst.ld,
-                      hw, P, C)
+    # z[n] = A[n] x[n] for every image in ONE launch (blockIdx.y = image)
+    gflops = 2.0 * N * hw * hw * C      # algorithmic FLOPs of one contraction (the zero padding of P is not counted)
+    ev = eng._t0("conv_igemm_kernel<128,128,false,1>(+splitk_epilogue)", gflops)
+    ops.gemm_rows_batched(aff, P, hw * P, xT, C * P, zdst.data, zdst.ld, hw * zdst.ld, hw, P, C, N)
+    eng._t1(ev)
     if eng.training:
         def bwd_contract():
             gz = zcat.grad[..., zoff:]
@@ -75,13 +77,15 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
             gxs = eng.grad_of(xs)
             if eng.wgrad_scratch is None:
                 eng.wgrad_scratch = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=eng.device)
-            for n in range(N):
-                # dA[q,p] = sum_c dz[q,c] x[p,c]   (B^T rows = p, K = c: x in its native layout)
-                ops.gemm_rows(gz[n].data_ptr(), zcat.ld, xs.data[n].data_ptr(), daff[n * hw:].data_ptr(), P,
-                              hw, C, hw)
-                # dx[p,c] = sum_q A[q,p] dz[q,c]   (K-major GEMM)
-                ops.gemm_kmajor(gz[n].data_ptr(), zcat.ld, aff[n * hw:].data_ptr(), P, gxs[n].data_ptr(),
-                                eng.wgrad_scratch, hw, C, hw, accumulate=xs.ginit)
+            # dA[n][q,p] = sum_c dz[q,c] x[p,c]   (B^T rows = p, K = c: x in its native layout), all images at once
+            ev = eng._t0("conv_igemm_kernel<128,128,false,1>(+splitk_epilogue)", gflops)
+            ops.gemm_rows_batched(gz, zcat.ld, hw * zcat.ld, xs.data, hw * xs.ld, daff, P, hw * P, hw, C, hw, N)
+            eng._t1(ev)
+            ev = eng._t0("conv_wgrad_kernel<128,128>+reduce", gflops)
+            # dx[n][p,c] = sum_q A[q,p] dz[q,c]   (K-major GEMM, all images at once)
+            ops.gemm_kmajor_batched(gz, zcat.ld, hw * zcat.ld, aff, P, hw * P, gxs, hw * xs.ld, eng.wgrad_scratch,
+                                    hw, C, hw, N, accumulate=xs.ginit)
+            eng._t1(ev)
             xs.ginit = True
             gym = eng.grad_of(ym)
             if psa.compact and typ == 0:

@@ -26,9 +26,48 @@ RATIO = 3.0
 FLOOR = 2e-7   # two fp32 ulps of the largest element: ops that are exact on the CPU (pure routing) have err_cpu = 0
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity, cgroup v2 cpu.max quota) — the GPU box shows 256
+    hardware threads in the affinity mask but grants 16; oversubscribing OpenMP by 16x stalls every CPU reference."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, torch.get_num_threads() if n > 64 else n))
+
+
 def _nchw(t, C):
     """NHWC device view (any channel stride) -> contiguous NCHW CPU fp32."""
     return t[..., :C].detach().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def conv_bwd_taps(x, w_shape, w, dy, stride, pad, dil, want_dx=True):
+    """fp64 conv backward as one GEMM per tap (multi-threaded BLAS): torch's own fp64 conv backward on the CPU
+    parallelises over the batch only, which is 2 here.  x [N,Ci,H,W], dy [N,Co,Ho,Wo] (any float dtype) ->
+    (dW [Co,Ci,R,S], dX or None) in fp64.  Checked against torch.nn.grad in tests/test_insitu_refs_cpu.py."""
+    Co, Ci, R, S = w_shape
+    N, _, H, W = x.shape
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    xp = F.pad(x.double(), (pad, pad, pad, pad))
+    dyf = dy.double().permute(1, 0, 2, 3).reshape(Co, N * Ho * Wo)                # [Co, NL]
+    dW = torch.empty(Co, Ci, R, S, dtype=torch.float64)
+    dxp = torch.zeros_like(xp) if want_dx else None
+    wd = None if w is None else w.double()
+    for r in range(R):
+        for s_ in range(S):
+            h0, w0 = r * dil, s_ * dil
+            sl = (slice(None), slice(None), slice(h0, h0 + (Ho - 1) * stride + 1, stride),
+                  slice(w0, w0 + (Wo - 1) * stride + 1, stride))
+            xs = xp[sl].permute(1, 0, 2, 3).reshape(Ci, N * Ho * Wo)              # [Ci, NL]
+            dW[:, :, r, s_] = dyf @ xs.t()
+            if want_dx:
+                g = (wd[:, :, r, s_].t() @ dyf).reshape(Ci, N, Ho, Wo).permute(1, 0, 2, 3)
+                dxp[sl] += g
+    dx = dxp[:, :, pad:pad + H, pad:pad + W].contiguous() if want_dx else None
+    return dW, dx
 
 
 def _err(a, ref):
@@ -43,7 +82,7 @@ class InsituChecker:
         self.log = log
         self.rows = []       # (kind, name, quantity, err_hip, err_cpu32)
         self.names = {m: n for n, m in eng.model.named_modules()}
-        torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+        torch.set_num_threads(usable_cores())
 
     # ------------------------------------------------------------------ hook
     def __call__(self, op):
@@ -91,13 +130,12 @@ class InsituChecker:
         gx0 = _nchw(x.grad, x.C) if (has_dx and x.ginit) else None
         self._launch(op)
         kw = dict(stride=cl.stride, padding=cl.pad, dilation=cl.dil)
-        gw64 = torch.nn.grad.conv2d_weight(xs.double(), w.shape, dy.double(), **kw)
+        gw64, gx64 = conv_bwd_taps(xs, w.shape, w, dy, cl.stride, cl.pad, cl.dil, want_dx=has_dx)
         gw32 = torch.nn.grad.conv2d_weight(xs, w.shape, dy, **kw)
         self._rec("conv", name, "wgrad", cl.wgrad.detach().cpu(), gw64, gw32)
         if m.bias is not None:
             self._rec("conv", name, "bgrad", cl.bgrad.detach().cpu(), dy.double().sum((0, 2, 3)), dy.sum((0, 2, 3)))
         if has_dx:
-            gx64 = torch.nn.grad.conv2d_input(xs.shape, w.double(), dy.double(), **kw)
             gx32 = torch.nn.grad.conv2d_input(xs.shape, w, dy, **kw)
             if gx0 is not None:
                 gx64 = gx64 + gx0.double()
@@ -164,7 +202,7 @@ class InsituChecker:
         dy = _nchw(y.grad, y.C)
         self._launch(op)
         kw = dict(stride=2, padding=1, dilation=1)
-        g64 = torch.nn.grad.conv2d_weight(xs.double(), m.weight.shape, dy.double(), **kw)
+        g64, _ = conv_bwd_taps(xs, m.weight.shape, None, dy, 2, 1, 1, want_dx=False)
         g32 = torch.nn.grad.conv2d_weight(xs, m.weight.shape, dy, **kw)
         self._rec("stem", self.names[m], "wgrad", self.eng.grad_views[m.weight].detach().cpu(), g64, g32)
 

@@ -4,7 +4,7 @@ against the right thing.  CPU only."""
 import torch
 import torch.nn.functional as F
 
-from insitu import InsituChecker
+from insitu import InsituChecker, conv_bwd_taps
 
 
 def test_bn_backward_formula_matches_autograd():
@@ -66,3 +66,17 @@ def test_psa_adjoint_formula_matches_autograd_of_the_oracle():
             dx, dmask = _psa_ref(gz, xv, A, alpha, softmax, typ, mh, mw, h, w)
             assert (dx.transpose(1, 2).reshape(N, C, h, w) - gx).abs().max() < 1e-12
             assert (dmask - gm).abs().max() < 1e-12
+
+
+def test_per_tap_conv_backward_matches_torch():
+    torch.manual_seed(2)
+    for (N, Ci, Co, H, k, s, p, d) in [(2, 5, 7, 11, 3, 1, 2, 2), (2, 4, 6, 13, 3, 2, 1, 1), (3, 6, 4, 9, 1, 1, 0, 1),
+                                       (2, 3, 5, 12, 1, 2, 0, 1), (1, 4, 4, 10, 3, 1, 4, 4)]:
+        x = torch.randn(N, Ci, H, H, dtype=torch.float64)
+        w = torch.randn(Co, Ci, k, k, dtype=torch.float64)
+        Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
+        dy = torch.randn(N, Co, Ho, Ho, dtype=torch.float64)
+        gw, gx = conv_bwd_taps(x.float().double(), w.shape, w, dy, s, p, d)
+        kw = dict(stride=s, padding=p, dilation=d)
+        assert (gw - torch.nn.grad.conv2d_weight(x.float().double(), w.shape, dy, **kw)).abs().max() < 1e-10
+        assert (gx - torch.nn.grad.conv2d_input(x.shape, w, dy, **kw)).abs().max() < 1e-10

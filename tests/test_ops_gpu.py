@@ -39,6 +39,44 @@ CONV_CASES = [
 ]
 
 
+WGRAD_BIG_CASES = [
+    # N, H, W, Ci, Co, k, stride, pad, dil  (Ci % 128 == 0, Co >= 128: the 128 x 128 weight-gradient tile)
+    (2, 13, 13, 128, 128, 3, 1, 2, 2),     # "same" dilated 3x3: linear gather with border taps out of range
+    (2, 17, 17, 128, 256, 3, 2, 1, 1),     # strided 3x3: generic gather
+    (5, 9, 9, 256, 150, 1, 1, 0, 1),       # 1x1, Co not a tile multiple (dy zero padded), M = 405 (K tail)
+    (2, 21, 21, 256, 512, 1, 2, 0, 1),     # strided 1x1 (downsample)
+    (3, 30, 30, 128, 128, 3, 1, 1, 1),     # M = 2700: several K splits
+]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", WGRAD_BIG_CASES)
+def test_wgrad_128_tile_variants(case, variant, report, monkeypatch):
+    """Every variant of the 128 x 128 weight-gradient kernel (0 register-staged, 1-5 direct-to-LDS rings with
+    out-of-range buffer offsets for padding taps / the K tail) against fp64; operands live in wider buffers."""
+    from semseg_amd import ops
+    monkeypatch.setenv("SEMSEG_WGRAD_SMALL", "0")
+    monkeypatch.setenv("SEMSEG_WGRAD_DMA", str(variant))
+    N, H, W, Ci, Co, k, s, p, d = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    Ho, Wo = ops.conv_out(H, k, s, p, d), ops.conv_out(W, k, s, p, d)
+    dy = torch.randn(N, Co, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, k, k), dy.double(), stride=s, padding=p, dilation=d)
+    ldx = Ci + 64
+    xb = torch.randn(N, H, W, ldx, device=DEV)
+    xb[..., 32:32 + Ci] = nhwc(x).to(DEV)
+    ldy = ops.roundup(Co, 128) + 128
+    dyb = torch.zeros(N, Ho, Wo, ldy, device=DEV)
+    dyb[..., :Co] = nhwc(dy).to(DEV)
+    scratch = torch.empty(ops.wgrad_scratch_floats(Ci, Co, k, k) * 4, device=DEV)
+    dw = torch.full((Co, Ci, k, k), float("nan"), device=DEV)
+    ops.conv_wgrad(xb[..., 32:], ldx, dyb, ldy, dw, scratch, N, H, W, Ci, Co, k, k, s, p, d)
+    e = relerr(dw, ref)
+    report("wgrad 128-tile variant %d %s: %.2e" % (variant, case, e))
+    assert e < 2e-5
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(case, report):
     from semseg_amd import ops
@@ -490,6 +528,45 @@ def test_gemm_entry_points(report):
     e = (relerr(Zd, Z), relerr(dAd[:hw, :hw], dA), relerr(dXd, dX))
     report("psa contraction gemms: fwd %.2e dA %.2e dX %.2e" % e)
     assert max(e) < 1e-5 and float(dAd[:hw, hw:].abs().max()) == 0.0
+
+
+def test_batched_gemm_entry_points(report):
+    """torch.bmm of model/psanet.py:90-91 and its two gradients as ONE launch per GEMM (blockIdx.y = image): the
+    batched forms of the two matrix-core kernels vs fp64, including accumulation into an existing dx and the
+    weight-gradient kernel variants (SEMSEG_WGRAD_DMA)."""
+    import os
+    from semseg_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, hw, C = 3, 100, 512
+    P = 128
+    A = torch.zeros(B * hw + 128, P); X = torch.zeros(B * hw + 128, C)
+    A[:B * hw, :hw] = torch.randn(B * hw, hw, generator=g)
+    X[:B * hw] = torch.randn(B * hw, C, generator=g)
+    A3, X3 = A[:B * hw, :hw].view(B, hw, hw).double(), X[:B * hw].view(B, hw, C).double()
+    Z = torch.bmm(A3, X3)
+    Ad, Xd = A.to(DEV), X.to(DEV)
+    XT = torch.zeros(B * C + 128, P, device=DEV)
+    ops.transpose_batched(Xd, C, hw * C, XT, P, C * P, B, hw, C)
+    Zd = torch.zeros(B, hw, 2 * C, device=DEV)                      # written into a channel slice (ld = 2C)
+    ops.gemm_rows_batched(Ad, P, hw * P, XT, C * P, Zd[..., C:], 2 * C, hw * 2 * C, hw, P, C, B)
+    dZ = torch.randn(B, hw, C, generator=g)
+    dA = torch.bmm(dZ.double(), X3.transpose(1, 2))
+    dX0 = torch.randn(B, hw, C, generator=g)
+    dX = torch.bmm(A3.transpose(1, 2), dZ.double()) + dX0.double()
+    dZd = dZ.to(DEV)
+    dAd = torch.zeros(B * hw + 128, P, device=DEV)
+    ops.gemm_rows_batched(dZd, C, hw * C, Xd, hw * C, dAd, P, hw * P, hw, C, hw, B)
+    scratch = torch.empty(16 * 1024 * 1024, device=DEV)
+    errs = []
+    for v in ("0", "2"):
+        os.environ["SEMSEG_WGRAD_DMA"] = v
+        dXd = dX0.to(DEV).clone()
+        ops.gemm_kmajor_batched(dZd, C, hw * C, Ad, P, hw * P, dXd, hw * C, scratch, hw, C, hw, B, accumulate=True)
+        errs.append(relerr(dXd, dX))
+    os.environ.pop("SEMSEG_WGRAD_DMA")
+    e = (relerr(Zd[..., C:], Z), relerr(dAd[:B * hw, :hw].view(B, hw, hw), dA), max(errs))
+    report("batched psa contraction gemms (%d images, one launch each): fwd %.2e dA %.2e dX %.2e" % ((B,) + e))
+    assert max(e) < 1e-5 and float(Zd[..., :C].abs().max()) == 0.0 and float(dAd[:, hw:].abs().max()) == 0.0
 
 
 def test_lib_psa_functional_dropin(report):
