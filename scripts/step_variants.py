@@ -1,0 +1,47 @@
+"""Whole-step A/B inside ONE process: the PSPNet-101 473^2 train step under combinations of
+  dma   = SEMSEG_WGRAD_DMA (weight-gradient kernel variant, read per launch),
+  side  = every weight gradient on the side stream (Engine.side_all),
+  hipri = dependent backward chain on a high-priority stream (Engine.hipri_main),
+interleaved over ROUNDS rounds.  python scripts/step_variants.py [batch] [rounds] [arch]"""
+import os, sys, time, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from semseg_amd.trainer import Trainer
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+ARCH = sys.argv[3] if len(sys.argv) > 3 else "psp"
+SIZE = 473 if ARCH == "psp" else 465
+CONFIGS = [tuple(int(v) for v in c.split(":")) for c in
+           os.environ.get("CONFIGS", "0:0:0,0:1:0,0:1:1,2:0:0,2:1:0,2:1:1,1:1:1,3:1:1,4:1:1").split(",")]
+torch.manual_seed(0)
+if ARCH == "psp":
+    from model.pspnet import PSPNet
+    model = PSPNet(layers=101, classes=150, zoom_factor=8, pretrained=False)
+else:
+    from model.psanet import PSANet
+    model = PSANet(layers=101, classes=150, zoom_factor=8, pretrained=False)
+model = model.cuda().train()
+tr = Trainer(model, base_lr=0.01, sync_bn=True)
+x = torch.randn(B, 3, SIZE, SIZE).cuda()
+y = torch.randint(0, 150, (B, SIZE, SIZE)).cuda()
+for _ in range(2):
+    tr.step(x, y, 0.01)
+eng = next(iter(tr.engines.values()))
+res = {c: [] for c in CONFIGS}
+for r in range(ROUNDS):
+    for c in CONFIGS:
+        dma, side, hipri = c
+        os.environ["SEMSEG_WGRAD_DMA"] = str(dma)
+        eng.side_all, eng.hipri_main = bool(side), bool(hipri)
+        tr.step(x, y, 0.01)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(5):
+            _, ml, _ = tr.step(x, y, 0.01)
+        torch.cuda.synchronize()
+        res[c].append((time.time() - t0) / 5 * 1e3)
+print("%s batch %d: ms per step (min over %d rounds / all)" % (ARCH, B, ROUNDS))
+for c in CONFIGS:
+    print("  dma %d side_all %d hipri %d : %8.2f   %s" % (c + (min(res[c]), " ".join("%.2f" % v for v in res[c]))))
+print("final loss", float(ml.item()))

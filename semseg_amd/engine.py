@@ -151,6 +151,10 @@ class Engine:
         # every weight gradient on the side stream (not only the small grids): the HBM-bound BatchNorm backward
         # kernels of the main stream then share the chip with MFMA-bound work instead of running alone
         self.side_all = os.environ.get("SEMSEG_SIDE_WGRAD_ALL", "0") == "1"
+        # run the dependent chain of backward (data gradients + BatchNorm) on a high-priority stream so that it wins
+        # the dispatch race against the weight gradients queued on the side stream
+        self.hipri_main = os.environ.get("SEMSEG_HIPRI_MAIN", "0") == "1"
+        self._hi = None
         self._side = None
         self._scr2 = None
         self._side_used = False
@@ -370,7 +374,7 @@ class Engine:
 
     def _scratch2(self):
         if self._scr2 is None:
-            self._scr2 = torch.empty((64 if self.side_all else 32) * 1024 * 1024, dtype=F32, device=self.device)
+            self._scr2 = torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device)
         return self._scr2
 
     def scratch(self):
@@ -732,6 +736,18 @@ class Engine:
         """Replays the tape; on return every parameter gradient is in self.grad_views."""
         self._reset_grad_flags()
         self._f64_zero_sums()
+        if self.hipri_main:
+            if self._hi is None:
+                self._hi = torch.cuda.Stream(device=self.device, priority=-1)
+            cur = torch.cuda.current_stream()
+            self._hi.wait_stream(cur)
+            with torch.cuda.stream(self._hi):
+                self._backward_chain(gmain, gaux)
+            cur.wait_stream(self._hi)
+        else:
+            self._backward_chain(gmain, gaux)
+
+    def _backward_chain(self, gmain, gaux):
         self._main = torch.cuda.current_stream()
         self._run(TapeOp("ce", lambda: self.ce_bwd(self._rec_main, gmain), dict(rec=self._rec_main, gloss=gmain, gmul=1.0)))
         self._run(TapeOp("ce", lambda: self.ce_bwd(self._rec_aux, gaux), dict(rec=self._rec_aux, gloss=gaux, gmul=1.0)))

@@ -8,7 +8,11 @@ backward on the CPU twice from those same operands: in fp64 (the reference value
 HIP path actually used, ReLU-mask flips and the conditioning of the network do not enter: a systematic error of
 1e-5 in any single dgrad / wgrad / BN-backward / CE-backward kernel shows up as a ratio >> 1.
 
-Criterion per quantity:  err_hip <= RATIO * err_cpu_fp32 + FLOOR,  err = max|a - ref64| / max|ref64|.
+Criterion per quantity, both against the fp64 recomputation:
+    rms error   ||a - ref||_2 / ||ref||_2   :  hip <= RATIO     * cpu_fp32 + FLOOR      (the noise LEVEL)
+    max error   max|a - ref| / max|ref|     :  hip <= RATIO_MAX * cpu_fp32 + FLOOR      (no outlier element)
+The rms is the statistic with the 3x bound: the maximum of ~1e6 rounding errors is itself a noisy sample (two fp32
+implementations of one sum differ by up to ~2.6x in it on the 73x73 case), so it gets the looser outlier bound.
 
 Reference formulas (file:line under /root/reference): conv backward = adjoints of nn.Conv2d (model/resnet.py:63-69,
 model/pspnet.py:65-77); BatchNorm backward = torch's batch_norm_backward for model/resnet.py:76-92 (train mode, biased
@@ -23,6 +27,7 @@ import torch
 import torch.nn.functional as F
 
 RATIO = 3.0
+RATIO_MAX = 5.0
 FLOOR = 2e-7   # two fp32 ulps of the largest element: ops that are exact on the CPU (pure routing) have err_cpu = 0
 
 
@@ -71,16 +76,19 @@ def conv_bwd_taps(x, w_shape, w, dy, stride, pad, dil, want_dx=True):
 
 
 def _err(a, ref):
+    """(max-abs error / max|ref|, rms error / rms ref)"""
     ref = ref.double()
+    diff = a.double() - ref
     d = float(ref.abs().max())
-    return float((a.double() - ref).abs().max()) / max(d, 1e-300)
+    r = float(ref.pow(2).mean().sqrt())
+    return float(diff.abs().max()) / max(d, 1e-300), float(diff.pow(2).mean().sqrt()) / max(r, 1e-300)
 
 
 class InsituChecker:
     def __init__(self, eng, log=print):
         self.eng = eng
         self.log = log
-        self.rows = []       # (kind, name, quantity, err_hip, err_cpu32)
+        self.rows = []       # (kind, name, quantity, max_hip, max_cpu32, rms_hip, rms_cpu32)
         self.names = {m: n for n, m in eng.model.named_modules()}
         torch.set_num_threads(usable_cores())
 
@@ -98,25 +106,28 @@ class InsituChecker:
         torch.cuda.synchronize()
 
     def _rec(self, kind, name, qty, hip, ref64, c32):
-        self.rows.append((kind, name, qty, _err(hip, ref64), _err(c32, ref64)))
+        mh, rh = _err(hip, ref64)
+        mc, rc = _err(c32, ref64)
+        self.rows.append((kind, name, qty, mh, mc, rh, rc))
 
     def failures(self):
-        return [r for r in self.rows if not (r[3] <= RATIO * r[4] + FLOOR)]
+        return [r for r in self.rows if not (r[5] <= RATIO * r[6] + FLOOR and r[3] <= RATIO_MAX * r[4] + FLOOR)]
 
     def summary(self):
         by = {}
-        for kind, name, qty, eh, ec in self.rows:
-            d = by.setdefault((kind, qty), [0, 0.0, 0.0, 0.0, ""])
+        for kind, name, qty, mh, mc, rh, rc in self.rows:
+            d = by.setdefault((kind, qty), [0, 0.0, 0.0, 0.0, "", 0.0])
             d[0] += 1
-            d[1] = max(d[1], eh)
-            d[2] = max(d[2], ec)
-            r = eh / max(ec, FLOOR / RATIO)
+            d[1] = max(d[1], rh)
+            d[2] = max(d[2], rc)
+            r = rh / max(rc, FLOOR / RATIO)
             if r > d[3]:
                 d[3], d[4] = r, name
+            d[5] = max(d[5], mh / max(mc, FLOOR / RATIO))
         out = []
-        for (kind, qty), (n, eh, ec, r, name) in sorted(by.items()):
-            out.append("  %-12s %-10s n=%3d  max err hip %.2e  cpu-fp32 %.2e  worst hip/cpu ratio %.2f (%s)"
-                       % (kind, qty, n, eh, ec, r, name))
+        for (kind, qty), (n, eh, ec, r, name, rm) in sorted(by.items()):
+            out.append("  %-10s %-8s n=%3d  rms err hip %.2e cpu-fp32 %.2e  worst rms ratio %.2f (%s), worst max-abs ratio %.2f"
+                       % (kind, qty, n, eh, ec, r, name, rm))
         return "\n".join(out)
 
     # ------------------------------------------------------------------ conv: dgrad, wgrad, bias grad
