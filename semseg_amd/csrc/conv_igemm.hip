@@ -862,6 +862,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
 // Fragments are read as ds_read_b64: lane l31 takes tile rows (2*l31, 2*l31+1), i.e. MFMA block i holds the rows
 // 2*r + i — a relabelling that only the epilogue sees (and which turns its stores into 8-byte lanes).
 // ------------------------------------------------------------------------------------------
+// 16 bytes per lane from a raw buffer straight into LDS at (wave-uniform lds + lane * 16).  The builtin only exists
+// for the device pass: on the host pass of a TEMPLATE kernel it silently suppresses the launch stub (ROCm 7.2), hence
+// the guard.
+__device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds, unsigned voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, 0, 0, 0);
+#endif
+}
+
 template <int MODE, int KS, int NSTAGE, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArgs pin) {
   WgradArgs p = pin;
@@ -925,7 +934,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
     float* Xsl = Ysl + KS * TM;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ry_, Ysl + (wave * RPW + 2 * i) * TM, 16, yoff[i], 0, 0, 0);
+      dma16_to_lds(ry_, Ysl + (wave * RPW + 2 * i) * TM, yoff[i]);
       yoff[i] += ystep;
     }
 #pragma unroll
@@ -948,7 +957,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
         else
           vo = ok ? (unsigned)((((n * p.Hin + ih) * p.Win + iw) * p.ldx + ci0 + col) * 4) : OOB;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, Xsl + (wave * RPW + 2 * i) * TN, 16, vo, 0, 0, 0);
+      dma16_to_lds(rx_, Xsl + (wave * RPW + 2 * i) * TN, vo);
       xoff[i] += xstep;
     }
   };
