@@ -9,6 +9,7 @@ def short(n):
 def family(k):
     """Template instantiations that bench.py's KernelTimer reports as one family: the weight-gradient kernel's
     addressing MODE and the forward/data-gradient kernel's two-level-accumulation flag are dropped."""
+    if k.startswith('conv_wgrad_dma_kernel<'): return 'conv_wgrad_dma_kernel<128x128>'
     m = re.match(r'conv_wgrad_kernel<(\d+), (\d+), \d+>', k)
     if m: return 'conv_wgrad_kernel<%s, %s>' % (m.group(1), m.group(2))
     m = re.match(r'conv_igemm_kernel<(\d+), (\d+), (true|false), (\d+), (true|false)>', k)
@@ -68,5 +69,5 @@ with open(os.path.join(ROOT, "profiles", tag + "_bench_family_stats.csv"), "w") 
     fo.write("family,calls,total_ms,avg_us\n")
     for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         fo.write('"%s",%d,%.3f,%.2f\n' % (k, c, t / 1e6, t / c / 1e3))
-wg = fam.get('conv_wgrad_kernel<128, 128>'); ru = fam.get('wgrad_reduce_unpack_kernel')
-if wg: print("rocprof family conv_wgrad_kernel<128,128>: avg %.1f us over %d launches (reduce kernel avg %.1f us)" % (wg[1] / wg[0] / 1e3, wg[0], ru[1] / ru[0] / 1e3 if ru else 0))
+wg = fam.get('conv_wgrad_dma_kernel<128x128>') or fam.get('conv_wgrad_kernel<128, 128>'); ru = fam.get('wgrad_reduce_unpack_kernel')
+if wg: print("rocprof family 128x128 weight-gradient kernel: avg %.1f us over %d launches (reduce kernel avg %.1f us)" % (wg[1] / wg[0] / 1e3, wg[0], ru[1] / ru[0] / 1e3 if ru else 0))

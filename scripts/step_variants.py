@@ -12,8 +12,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ARCH = sys.argv[3] if len(sys.argv) > 3 else "psp"
 SIZE = 473 if ARCH == "psp" else 465
-CONFIGS = [tuple(int(v) for v in c.split(":")) for c in
-           os.environ.get("CONFIGS", "0:0:0,0:1:0,0:1:1,2:0:0,2:1:0,2:1:1,1:1:1,3:1:1,4:1:1").split(",")]
+# "policy/side/hipri", policy = SEMSEG_WGRAD_DMA value (a variant number or "small:big:tile-threshold")
+CONFIGS = [(c.split("/")[0], int(c.split("/")[1]), int(c.split("/")[2])) for c in
+           os.environ.get("CONFIGS", "0/0/0,3/1/1,1/1/1,2/1/1,1:3:32/1/1,1:2:32/1/1,1:3:32/1/0,1:3:32/0/0,"
+                                     "1:2:32/0/0,3/0/0").split(",")]
 torch.manual_seed(0)
 if ARCH == "psp":
     from model.pspnet import PSPNet
@@ -43,5 +45,5 @@ for r in range(ROUNDS):
         res[c].append((time.time() - t0) / 5 * 1e3)
 print("%s batch %d: ms per step (min over %d rounds / all)" % (ARCH, B, ROUNDS))
 for c in CONFIGS:
-    print("  dma %d side_all %d hipri %d : %8.2f   %s" % (c + (min(res[c]), " ".join("%.2f" % v for v in res[c]))))
+    print("  dma %-8s side_all %d hipri %d : %8.2f   %s" % (c + (min(res[c]), " ".join("%.2f" % v for v in res[c]))))
 print("final loss", float(ml.item()))

@@ -12,6 +12,7 @@
 // Tile: 256 threads = 4 waves (2x2), block tile BM x BN x 32, each wave (BM/2)x(BN/2) as
 // 32x32 MFMA blocks; global->register prefetch of K-step t+1 overlaps the MFMAs of step t.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "common.h"
@@ -1350,26 +1351,39 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   const int ksteps = (M + 31) / 32;
   a.batch = batch; a.x_bs = x_bs; a.dy_bs = dy_bs;
   scratch_floats /= batch;   // every batch item owns its own slab set
-  // Direct-to-LDS variant of the 128 x 128 kernel (SEMSEG_WGRAD_DMA = 1..5 picks K-step / ring depth / residency;
-  // 0 = register-staged kernel).  Needs byte offsets below 2^31 for both operands.
-#ifndef WGRAD_DMA_DEFAULT
-#define WGRAD_DMA_DEFAULT 0
+  // Direct-to-LDS variants of the 128 x 128 kernel (1..5 = K-step / ring depth / residency; 0 = register-staged
+  // kernel).  They need byte offsets below 2^31 for both operands.
+  // Variant choice.  SEMSEG_WGRAD_DMA = 0..5 forces one variant (read per call: tuning scripts switch inside one
+  // process); "a:b:t" = variant a for grids of <= t tiles, b above; unset = WGRAD_DMA_POLICY.  Measured at bs 16
+  // (DESIGN.md section 8.2): kernel by kernel the three rings are within 1.5 % of each other (55.2-56.0 ms per
+  // step vs 58.3 for the register-staged kernel; KS 32 best on the short 1x1 grids, KS 16 x 3 on cls.0), but inside
+  // the step, where the weight gradients share the chip with the main stream, the 2-workgroup-per-CU ring (3) wins
+  // for every layer (207.9 ms vs 210.1 for "1:3:32" and 212.2 for 2).
+#ifndef WGRAD_DMA_POLICY
+#define WGRAD_DMA_POLICY "3"
 #endif
-  const char* dma_s = getenv("SEMSEG_WGRAD_DMA");   // read per call: scripts switch variants inside one process
-  const int dma_env = dma_s ? atoi(dma_s) : WGRAD_DMA_DEFAULT;
+  const char* dma_s = getenv("SEMSEG_WGRAD_DMA");
+  if (!dma_s) dma_s = WGRAD_DMA_POLICY;
+  int dma_env = atoi(dma_s);
+  if (const char* c1 = strchr(dma_s, ':')) {
+    const int vb = atoi(c1 + 1);
+    const char* c2 = strchr(c1 + 1, ':');
+    const int thr = c2 ? atoi(c2 + 1) : 32;
+    if (tiles > thr) dma_env = vb;
+  }
   const bool dma_ok = (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
-  const int dma = (big && dma_ok) ? dma_env : 0;
+  const int dma = (big && dma_ok && dma_env >= 0 && dma_env <= 5) ? dma_env : 0;
   static const int occ_of[6] = {3, 2, 3, 2, 5, 5};
-  // aim at one full residency round (256 CUs x resident workgroups per CU) without spilling into a second
-  const int ROUND = 256 * occ_of[dma < 0 || dma > 5 ? 0 : dma];
-  int ksplit = ROUND / (tiles * batch);
-  if (tiles * batch > ROUND / 2) {
-    // more than half a round of tiles already: pick the K split whose workgroup count fills whole
-    // residency rounds best (e.g. cls.0: 1152 tiles -> x2 = 2304 = 3 rounds exactly)
+  // Fill whole residency rounds (256 CUs x resident workgroups per CU): among the K splits that give at most two
+  // rounds, take the one with the best fill (ties: fewer splits = fewer slabs to write and reduce).
+  const int ROUND = 256 * occ_of[dma];
+  const int wg1 = tiles * batch;     // workgroups per K slice
+  int ksplit = 1;
+  {
     double best = 0.0;
-    ksplit = 1;
-    for (int ks = 1; ks <= 8; ++ks) {
-      const int wgs = tiles * batch * ks;
+    const int ks_max = wg1 > ROUND / 2 ? 8 : (2 * ROUND + wg1 - 1) / wg1;
+    for (int ks = 1; ks <= ks_max; ++ks) {
+      const int wgs = wg1 * ks;
       const double eff = (double)wgs / (double)(((wgs + ROUND - 1) / ROUND) * ROUND);
       if (eff > best + 0.02) { best = eff; ksplit = ks; }
     }

@@ -52,9 +52,12 @@ class KernelTimer:
                       "tflops": round(fl / t / 1e12, 2) if t > 0 else None}
         return out
 
-    def roofline(self, peak_tflops):
+    def roofline(self, peak_tflops, family=None):
         fam = self._collect()
-        k, (n, fl, t) = max(fam.items(), key=lambda kv: kv[1][2])
+        if family is not None:
+            k, (n, fl, t) = family, fam[family]
+        else:
+            k, (n, fl, t) = max(fam.items(), key=lambda kv: kv[1][2])
         ach = fl / t / 1e12
         return {"kernel": k, "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tflops,
                 "unit": "TFLOP/s", "frac": round(ach / peak_tflops, 4), "traffic": None,
@@ -148,12 +151,15 @@ class Engine:
         self.ktimer = None
         self._eval_epoch = 0
         self.side_wgrad = os.environ.get("SEMSEG_SIDE_WGRAD", "1") == "1"
-        # every weight gradient on the side stream (not only the small grids): the HBM-bound BatchNorm backward
-        # kernels of the main stream then share the chip with MFMA-bound work instead of running alone
-        self.side_all = os.environ.get("SEMSEG_SIDE_WGRAD_ALL", "0") == "1"
-        # run the dependent chain of backward (data gradients + BatchNorm) on a high-priority stream so that it wins
-        # the dispatch race against the weight gradients queued on the side stream
-        self.hipri_main = os.environ.get("SEMSEG_HIPRI_MAIN", "0") == "1"
+        # Every weight gradient runs on the side stream (not only the small grids): the direct-to-LDS weight-gradient
+        # kernel leaves >= 60 % of the VGPR file and 32 KB of LDS per CU free, so the HBM-bound BatchNorm backward
+        # kernels and the data-gradient GEMMs of the main stream are co-resident with it instead of running alone
+        # (measured bs 16: 217.4 -> 207.9 ms per step together with the high-priority chain below, 214.5 without
+        # the side stream; scripts/step_variants.py).
+        self.side_all = os.environ.get("SEMSEG_SIDE_WGRAD_ALL", "1") == "1"
+        # The dependent chain of backward (data gradients + BatchNorm) runs on a high-priority stream so that it wins
+        # the dispatch race against the weight gradients queued on the side stream.
+        self.hipri_main = os.environ.get("SEMSEG_HIPRI_MAIN", "1") == "1"
         self._hi = None
         self._side = None
         self._scr2 = None
@@ -326,7 +332,8 @@ class Engine:
         dy = y.grad
         flops = 2.0 * y.M * cl.Co * cl.Ci * cl.R * cl.S
         big = cl.Ci % 128 == 0 and cl.Co >= 128
-        ev = self._t0("conv_wgrad_kernel<%d,%d>+reduce" % ((128, 128) if big else (64, 64)), flops)
+        # 128 x 128 tiles run the direct-to-LDS kernel (conv_igemm.hip: WGRAD_DMA_POLICY), 64 x 64 the register-staged one
+        ev = self._t0("conv_wgrad_dma_kernel<128x128>+reduce" if big else "conv_wgrad_kernel<64,64>+reduce", flops)
         ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
                        cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil)
         self._t1(ev)

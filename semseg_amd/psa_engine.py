@@ -81,7 +81,7 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
             ev = eng._t0("conv_igemm_kernel<128,128,false,1>(+splitk_epilogue)", gflops)
             ops.gemm_rows_batched(gz, zcat.ld, hw * zcat.ld, xs.data, hw * xs.ld, daff, P, hw * P, hw, C, hw, N)
             eng._t1(ev)
-            ev = eng._t0("conv_wgrad_kernel<128,128>+reduce", gflops)
+            ev = eng._t0("conv_wgrad_dma_kernel<128x128>+reduce", gflops)
             # dx[n][p,c] = sum_q A[q,p] dz[q,c]   (K-major GEMM, all images at once)
             ops.gemm_kmajor_batched(gz, zcat.ld, hw * zcat.ld, aff, P, hw * P, gxs, hw * xs.ld, eng.wgrad_scratch,
                                     hw, C, hw, N, accumulate=xs.ginit)
