@@ -12,10 +12,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ARCH = sys.argv[3] if len(sys.argv) > 3 else "psp"
 SIZE = 473 if ARCH == "psp" else 465
-# "policy/side/hipri", policy = SEMSEG_WGRAD_DMA value (a variant number or "small:big:tile-threshold")
-CONFIGS = [(c.split("/")[0], int(c.split("/")[1]), int(c.split("/")[2])) for c in
-           os.environ.get("CONFIGS", "0/0/0,3/1/1,1/1/1,2/1/1,1:3:32/1/1,1:2:32/1/1,1:3:32/1/0,1:3:32/0/0,"
-                                     "1:2:32/0/0,3/0/0").split(",")]
+# "policy/side/hipri/convdma": policy = SEMSEG_WGRAD_DMA value (a variant number or "small:big:tile-threshold"),
+# convdma = SEMSEG_CONV_DMA (forward / data-gradient kernel: 0 register-staged, 1 direct-to-LDS, 2 only 3x3, 3 only 1x1)
+CONFIGS = [(c.split("/")[0], int(c.split("/")[1]), int(c.split("/")[2]), int(c.split("/")[3])) for c in
+           os.environ.get("CONFIGS", "0/0/0/0,3/1/1/0,3/1/1/1,6/1/1/0,6/1/1/1,7/1/1/1,3/1/1/2,3/1/1/3,6/0/0/1").split(",")]
 torch.manual_seed(0)
 if ARCH == "psp":
     from model.pspnet import PSPNet
@@ -33,8 +33,9 @@ eng = next(iter(tr.engines.values()))
 res = {c: [] for c in CONFIGS}
 for r in range(ROUNDS):
     for c in CONFIGS:
-        dma, side, hipri = c
+        dma, side, hipri, cdma = c
         os.environ["SEMSEG_WGRAD_DMA"] = str(dma)
+        os.environ["SEMSEG_CONV_DMA"] = str(cdma)
         eng.side_all, eng.hipri_main = bool(side), bool(hipri)
         tr.step(x, y, 0.01)
         torch.cuda.synchronize()
@@ -45,5 +46,5 @@ for r in range(ROUNDS):
         res[c].append((time.time() - t0) / 5 * 1e3)
 print("%s batch %d: ms per step (min over %d rounds / all)" % (ARCH, B, ROUNDS))
 for c in CONFIGS:
-    print("  dma %-8s side_all %d hipri %d : %8.2f   %s" % (c + (min(res[c]), " ".join("%.2f" % v for v in res[c]))))
+    print("  wgrad %-8s side_all %d hipri %d conv_dma %d : %8.2f   %s" % (c + (min(res[c]), " ".join("%.2f" % v for v in res[c]))))
 print("final loss", float(ml.item()))

@@ -76,6 +76,15 @@ __device__ __forceinline__ int fdiv(int n, FastDiv f) {
 // block (measured: -13 % on every conv).
 __device__ __attribute__((aligned(16))) float g_zero_line[32] = {0};
 
+// 16 bytes per lane from a raw buffer straight into LDS at (wave-uniform lds + lane * 16); voffset per lane, soffset
+// scalar.  The builtin only exists for the device pass: on the host pass of a TEMPLATE kernel it silently suppresses the
+// launch stub (ROCm 7.2), hence the guard.
+__device__ __forceinline__ void dma16_to_lds_s(__amdgpu_buffer_rsrc_t rsrc, float* lds, unsigned voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, soffset, 0, 0);
+#endif
+}
+
 struct ConvArgs {
   const float* x;   // A source: activations (fwd) or output-gradient (dgrad), NHWC
   const float* w;   // packed B^T panel [Nout_pad][KT*32]
@@ -106,6 +115,120 @@ struct ConvArgs {
   int batch;
   long long x_bs, w_bs, y_bs, add_bs;
 };
+
+// ---- epilogue shared by the register-staged and the direct-to-LDS kernels ----
+template <int BM, int BN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2][BN / 64], float* smem, bool split,
+                                              int ks, int m0, int n0, int tile_m) {
+  constexpr int NT = BM * 2;
+  constexpr int MREP = 2, NREP = BN / 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // The MFMA accumulator layout gives each lane ONE column and 32 rows of its wave's 64 x 32 block: a
+  // direct store is 32 dword stores per lane and is store-issue bound (~16k cycles per tile, 30 % of a
+  // K = 256 tile).  Each wave therefore transposes block by block through its private 64 x 36-float LDS
+  // slab and stores 16-byte lanes (8 per block instead of 32); bias / residual add ride along.
+  // Statistics are taken from the accumulators (+bias) in registers, in fp64.
+  const int Nout4 = (p.Nout + 3) & ~3;
+  float* const dst = split ? p.part + (size_t)ks * (p.M - p.tail_m0) * p.ldpart : p.y;
+  const int ldd = split ? p.ldpart : p.ldy;
+  const int mrow0 = split ? p.tail_m0 : 0;           // partial slabs start at the tail's first row
+  const int colmax = split ? p.ldpart : Nout4;       // widest column a 16-byte store may touch
+  const bool wide = split || ((p.ldy & 3) == 0 && p.ldy >= Nout4 && (!p.add || (p.ldadd & 3) == 0));
+  float* wl = smem + wave * (64 * LDK);              // this wave's slab (needs >= NT/64 * 64 * LDK floats)
+  double* red = reinterpret_cast<double*>(smem);     // [BM/64 (wm)][BN][2], used after the stores
+  double st1[NREP], st2[NREP];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int lcol = wn * (BN / 2) + j * 32 + l31;
+    const int col = n0 + lcol;
+    const bool cok = col < p.Nout;
+    const float bv = (!split && p.bias && cok) ? p.bias[col] : 0.f;
+    const float sv = (!split && p.scale && cok) ? p.scale[col] : 1.f;
+    const bool relu = !split && p.relu;
+    double s1 = 0.0, s2 = 0.0;
+    if (wide) {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          const float v = acc[i][j][e] * sv + bv;
+          wl[lr * LDK + l31] = v;
+          if (m0 + wm * 64 + lr < p.M && cok) {
+            const double dv = (double)v;
+            s1 += dv;
+            s2 += dv * dv;
+          }
+        }
+      // same-wave LDS traffic is ordered: no barrier needed between the writes above and these reads
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int idx = lane + 64 * t;
+        const int lr = idx >> 3, c4 = (idx & 7) * 4;
+        const int m = m0 + wm * 64 + lr;
+        const int cg = n0 + wn * (BN / 2) + j * 32 + c4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&wl[lr * LDK + c4]);
+        if (m < p.M && cg < colmax) {
+          if (!split && p.add) v += *reinterpret_cast<const f32x4*>(p.add + (size_t)m * p.ldadd + cg);
+          if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(dst + (size_t)(m - mrow0) * ldd + cg) = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          if (m < p.M && cok) {
+            float v = acc[i][j][e] * sv + bv;
+            const double dv = (double)v;
+            s1 += dv;
+            s2 += dv * dv;
+            if (p.add) v += p.add[(size_t)m * p.ldadd + col];
+            if (relu) v = fmaxf(v, 0.f);
+            p.y[(size_t)m * p.ldy + col] = v;
+          }
+        }
+    }
+    st1[j] = s1;
+    st2[j] = s2;
+  }
+  if (!split && p.stats) {
+    __syncthreads();  // every wave is done with its transposition slab
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int lcol = wn * (BN / 2) + j * 32 + l31;
+      const double s1 = st1[j] + shfl_xor_f64(st1[j], 32);
+      const double s2 = st2[j] + shfl_xor_f64(st2[j], 32);
+      if (lhi == 0) {
+        red[(wm * BN + lcol) * 2 + 0] = s1;
+        red[(wm * BN + lcol) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int col = n0 + tid;
+      if (col < p.Nout) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < BM / 64; ++r) {
+          s1 += red[(r * BN + tid) * 2 + 0];
+          s2 += red[(r * BN + tid) * 2 + 1];
+        }
+        double* st = p.stats + (size_t)(tile_m % p.stats_nslot) * 2 * p.Nout;
+        atomic_add_f64(&st[col], s1);
+        atomic_add_f64(&st[p.Nout + col], s2);
+      }
+    }
+  }
+}
 
 // RS_T == 0: generic tap walk with global loads.  RS_T == 1 / 9 (1x1 / 3x3): the tap loop is unrolled
 // and the gather uses buffer loads with per-(row,tap) byte offsets precomputed in VGPRs (invalid taps
@@ -463,109 +586,246 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
         for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
   }
 
-  // ---- epilogue ----
-  // The MFMA accumulator layout gives each lane ONE column and 32 rows of its wave's 64 x 32 block: a
-  // direct store is 32 dword stores per lane and is store-issue bound (~16k cycles per tile, 30 % of a
-  // K = 256 tile).  Each wave therefore transposes block by block through its private 64 x 36-float LDS
-  // slab and stores 16-byte lanes (8 per block instead of 32); bias / residual add ride along.
-  // Statistics are taken from the accumulators (+bias) in registers, in fp64.
-  const int Nout4 = (p.Nout + 3) & ~3;
-  float* const dst = split ? p.part + (size_t)ks * (p.M - p.tail_m0) * p.ldpart : p.y;
-  const int ldd = split ? p.ldpart : p.ldy;
-  const int mrow0 = split ? p.tail_m0 : 0;           // partial slabs start at the tail's first row
-  const int colmax = split ? p.ldpart : Nout4;       // widest column a 16-byte store may touch
-  const bool wide = split || ((p.ldy & 3) == 0 && p.ldy >= Nout4 && (!p.add || (p.ldadd & 3) == 0));
-  float* wl = smem + wave * (64 * LDK);              // this wave's slab (needs >= NT/64 * 64 * LDK floats)
-  double* red = reinterpret_cast<double*>(smem);     // [BM/64 (wm)][BN][2], used after the stores
-  double st1[NREP], st2[NREP];
+  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m);
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward / data-gradient, direct-to-LDS variant (1x1 and 3x3 taps, 128-row tiles).  Same gather as the
+// buffer-load path above (per-(row, tap) byte offsets, out-of-range offsets for padding taps and rows past M,
+// which the buffer unit turns into zeros), but the 16-byte pieces go straight into LDS with
+// `buffer_load_dwordx4 ... lds` — no staging registers, no ds_write pass — into a 2-stage ring with ONE raw
+// s_barrier per K-step.  An LDS-DMA wave instruction writes 1 KiB lane-linearly = 8 K-contiguous rows of 128 B, so
+// the rows cannot be padded; bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the
+// 16-byte chunk index with ((row >> 1) & 7), applied on the SOURCE side (which chunk a lane fetches) and again on
+// the read side (cdna_hip_programming.md, rule 21): the 16 rows of a ds_read_b128 lane group then hit 16 different
+// 16-byte slots of the 256-byte bank row.
+// ------------------------------------------------------------------------------------------
+template <int BN, bool TR, int RS_T, bool TL>
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const ConvArgs pin) {
+  constexpr int BM = 128;
+  ConvArgs p = pin;
+  if (p.batch > 1) {
+    const long long bz = blockIdx.y;
+    p.x += bz * p.x_bs;
+    p.w += bz * p.w_bs;
+    p.y += bz * p.y_bs;
+    if (p.add) p.add += bz * p.add_bs;
+  }
+  constexpr int MREP = 2, NREP = BN / 64;
+  constexpr int A_PER = 4, B_PER = BN / 32;      // DMA instructions per wave per K-step (8 rows each)
+  constexpr int STAGE = (BM + BN) * BK;          // floats per ring slot, rows unpadded
+  constexpr int EPI = 4 * 64 * LDK;
+  constexpr int SMEM_F = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  int ks = 0, tile;
+  bool split = false;
+  if ((int)blockIdx.x < p.full_tiles) {
+    tile = xcd_remap(blockIdx.x, p.full_tiles);
+  } else {
+    const int u = xcd_remap(blockIdx.x - p.full_tiles, gridDim.x - p.full_tiles);
+    const int uq = fdiv(u, p.div_ks);
+    ks = u - uq * p.ksplit;
+    tile = p.full_tiles + uq;
+    split = p.ksplit > 1;
+  }
+  const int tile_m = fdiv(tile, p.div_tn);
+  const int tile_n = tile - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int nchunk = p.Kc / BK;
+  const int KT_all = RS_T * nchunk;
+  const size_t wK = (size_t)KT_all * BK;
+  const int kt0 = split ? ks * p.kt_per : 0;
+  const int KT = split ? min(KT_all, kt0 + p.kt_per) : KT_all;
+
+  // ---- DMA assignment: instruction i of this wave covers tile rows wave*32 + i*8 + (lane >> 3) (A) and
+  // wave*(BN/4) + i*8 + (lane >> 3) (B); lane & 7 is the LDS chunk position, which holds the source chunk
+  // (lane & 7) ^ ((row >> 1) & 7).  (row >> 1) & 7 = (4*i + (lane >> 4)) & 7 for both operands.
+  const int rsub = lane >> 3;
+  unsigned baseA[A_PER], maskA[A_PER];
 #pragma unroll
-  for (int j = 0; j < NREP; ++j) {
-    const int lcol = wn * (BN / 2) + j * 32 + l31;
-    const int col = n0 + lcol;
-    const bool cok = col < p.Nout;
-    const float bv = (!split && p.bias && cok) ? p.bias[col] : 0.f;
-    const float sv = (!split && p.scale && cok) ? p.scale[col] : 1.f;
-    const bool relu = !split && p.relu;
-    double s1 = 0.0, s2 = 0.0;
-    if (wide) {
-#pragma unroll
-      for (int i = 0; i < MREP; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          const float v = acc[i][j][e] * sv + bv;
-          wl[lr * LDK + l31] = v;
-          if (m0 + wm * 64 + lr < p.M && cok) {
-            const double dv = (double)v;
-            s1 += dv;
-            s2 += dv * dv;
-          }
-        }
-      // same-wave LDS traffic is ordered: no barrier needed between the writes above and these reads
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int idx = lane + 64 * t;
-        const int lr = idx >> 3, c4 = (idx & 7) * 4;
-        const int m = m0 + wm * 64 + lr;
-        const int cg = n0 + wn * (BN / 2) + j * 32 + c4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&wl[lr * LDK + c4]);
-        if (m < p.M && cg < colmax) {
-          if (!split && p.add) v += *reinterpret_cast<const f32x4*>(p.add + (size_t)m * p.ldadd + cg);
-          if (relu) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-          }
-          *reinterpret_cast<f32x4*>(dst + (size_t)(m - mrow0) * ldd + cg) = v;
-        }
-      }
+  for (int i = 0; i < A_PER; ++i) {
+    const int m = m0 + wave * 32 + i * 8 + rsub;
+    const bool rok = m < p.M;
+    const int mm = rok ? m : 0;
+    const int hw = p.Hout * p.Wout;
+    const int n = fdiv(mm, p.div_hw);
+    const int rem = mm - n * hw;
+    const int oh = fdiv(rem, p.div_w);
+    const int ow = rem - oh * p.Wout;
+    unsigned mask = 0;
+    int bh, bw;
+    if (!TR) {
+      bh = oh * p.stride - p.pad;
+      bw = ow * p.stride - p.pad;
     } else {
+      bh = (oh + p.pad) / p.stride;
+      bw = (ow + p.pad) / p.stride;
+    }
+    for (int r = 0; r < p.R; ++r)
+      for (int s_ = 0; s_ < p.S; ++s_) {
+        bool ok = rok;
+        int ih, iw;
+        if (!TR) {
+          ih = bh + r * p.dil;
+          iw = bw + s_ * p.dil;
+        } else {
+          const int rd = r * p.dil, sd = s_ * p.dil;
+          ih = bh - rd / p.stride;
+          iw = bw - sd / p.stride;
+          ok = ok && ((oh + p.pad) % p.stride == rd % p.stride) && ((ow + p.pad) % p.stride == sd % p.stride);
+        }
+        ok = ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
+        if (ok) mask |= 1u << (r * p.S + s_);
+      }
+    const int csrc = (lane & 7) ^ ((4 * i + (lane >> 4)) & 7);
+    maskA[i] = mask;
+    baseA[i] = (unsigned)((((n * p.Hin + bh) * p.Win + bw) * p.ldx + csrc * 4) * 4);
+  }
+  unsigned voffB[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int csrc = (lane & 7) ^ ((4 * i + (lane >> 4)) & 7);
+    voffB[i] = (unsigned)(((size_t)(n0 + wave * (BN / 4) + i * 8 + rsub) * wK + csrc * 4) * 4);
+  }
+  int toffs[RS_T];
+#pragma unroll
+  for (int t = 0; t < RS_T; ++t) {
+    const int r = t / p.S, s_ = t - (t / p.S) * p.S;
+    if (!TR)
+      toffs[t] = (r * p.dil * p.Win + s_ * p.dil) * p.ldx * 4;
+    else
+      toffs[t] = -(((r * p.dil) / p.stride) * p.Win + (s_ * p.dil) / p.stride) * p.ldx * 4;
+  }
+  const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x80000000, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x80000000, 0x00020000);
+
+  auto issue = [&](auto tapc, int c, int slot) {
+    constexpr int t = decltype(tapc)::value;
+    float* As = smem + slot * STAGE;
+    float* Bs = As + BM * BK;
+    const int so_a = c * (BK * 4);
+    const int so_b = (c * RS_T + t) * (BK * 4);
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const unsigned vo = ((maskA[i] >> t) & 1u) ? baseA[i] + (unsigned)toffs[t] : OOB;
+      dma16_to_lds_s(rx_, As + (wave * 32 + i * 8) * BK, vo, so_a);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) dma16_to_lds_s(rw_, Bs + (wave * (BN / 4) + i * 8) * BK, voffB[i], so_b);
+  };
+
+  f32x16 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  constexpr bool TWO_LEVEL = CONV_TWO_LEVEL && TL;
+  f32x16 acc2[TWO_LEVEL ? MREP : 1][TWO_LEVEL ? NREP : 1];
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+  }
+  auto flush = [&] {
+    if constexpr (TWO_LEVEL) {
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          if (m < p.M && cok) {
-            float v = acc[i][j][e] * sv + bv;
-            const double dv = (double)v;
-            s1 += dv;
-            s2 += dv * dv;
-            if (p.add) v += p.add[(size_t)m * p.ldadd + col];
-            if (relu) v = fmaxf(v, 0.f);
-            p.y[(size_t)m * p.ldy + col] = v;
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            acc2[i][j][e] += acc[i][j][e];
+            acc[i][j][e] = 0.f;
           }
-        }
     }
-    st1[j] = s1;
-    st2[j] = s2;
-  }
-  if (!split && p.stats) {
-    __syncthreads();  // every wave is done with its transposition slab
+  };
+
+  // fragment addressing: tile row (wm*64 + i*32 + l31) or (wn*BN/2 + j*32 + l31); chunk (k8*2 + lhi) ^ ((l31 >> 1) & 7)
+  const int rsw = (l31 >> 1) & 7;
+  int koff[4];
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) {
-      const int lcol = wn * (BN / 2) + j * 32 + l31;
-      const double s1 = st1[j] + shfl_xor_f64(st1[j], 32);
-      const double s2 = st2[j] + shfl_xor_f64(st2[j], 32);
-      if (lhi == 0) {
-        red[(wm * BN + lcol) * 2 + 0] = s1;
-        red[(wm * BN + lcol) * 2 + 1] = s2;
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const int col = n0 + tid;
-      if (col < p.Nout) {
-        double s1 = 0.0, s2 = 0.0;
+  for (int k8 = 0; k8 < 4; ++k8) koff[k8] = (((k8 * 2 + lhi) ^ rsw) * 4);
+  const int arow = (wm * 64 + l31) * BK;
+  const int brow = (BM + wn * (BN / 2) + l31) * BK;
+
+  auto compute = [&](int slot) {
+    const float* base = smem + slot * STAGE;
 #pragma unroll
-        for (int r = 0; r < BM / 64; ++r) {
-          s1 += red[(r * BN + tid) * 2 + 0];
-          s2 += red[(r * BN + tid) * 2 + 1];
-        }
-        double* st = p.stats + (size_t)(tile_m % p.stats_nslot) * 2 * p.Nout;
-        atomic_add_f64(&st[col], s1);
-        atomic_add_f64(&st[p.Nout + col], s2);
-      }
+    for (int k8 = 0; k8 < 4; ++k8) {
+      f32x4 a[MREP], b[NREP];
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) a[i] = *reinterpret_cast<const f32x4*>(base + arow + i * 32 * BK + koff[k8]);
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) b[j] = *reinterpret_cast<const f32x4*>(base + brow + j * 32 * BK + koff[k8]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
     }
+  };
+
+  const int c_begin = kt0 / RS_T, c_end = KT / RS_T;
+  int slot = 0;
+  auto step = [&](auto tapc, int c) {
+    constexpr int t = decltype(tapc)::value;
+    // this K-step's tile has landed for this wave (only one stage is ever in flight) ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and for every wave after the barrier, which also says: everybody is done reading the other slot
+    __builtin_amdgcn_s_barrier();
+    if constexpr (t + 1 < RS_T) {
+      issue(std::integral_constant<int, t + 1>{}, c, slot ^ 1);
+    } else {
+      if (c + 1 < c_end) issue(std::integral_constant<int, 0>{}, c + 1, slot ^ 1);
+    }
+    compute(slot);
+    slot ^= 1;
+  };
+  if (c_begin < c_end) issue(std::integral_constant<int, 0>{}, c_begin, 0);
+  for (int c = c_begin; c < c_end; ++c) {
+    step(std::integral_constant<int, 0>{}, c);
+    if constexpr (RS_T == 9) {
+      step(std::integral_constant<int, 1>{}, c);
+      step(std::integral_constant<int, 2>{}, c);
+      step(std::integral_constant<int, 3>{}, c);
+      step(std::integral_constant<int, 4>{}, c);
+      step(std::integral_constant<int, 5>{}, c);
+      step(std::integral_constant<int, 6>{}, c);
+      step(std::integral_constant<int, 7>{}, c);
+      step(std::integral_constant<int, 8>{}, c);
+    }
+    // bound the fp32 MFMA chain to 576 (3x3: two channel blocks x 9 taps) / 512 (1x1) products: the chain's
+    // rounding noise grows ~sqrt(length) while a blocked CPU sum does not (in-situ backward parity)
+    if (((c - c_begin) & (RS_T == 9 ? 1 : 15)) == (RS_T == 9 ? 1 : 15)) flush();
   }
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
+  }
+  // no DMA is outstanding here (the last step issued none, its wait drained the queue); the ring is reused as the
+  // epilogue's transposition slabs once every wave has left the K loop
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m);
 }
 
 // Split-K epilogue: y = sum_ks part[ks] (+bias) (+add); optional fp64 channel statistics.
@@ -872,7 +1132,7 @@ __device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, float*
 #endif
 }
 
-template <int MODE, int KS, int NSTAGE, int OCC>
+template <int MODE, int KS, int NSTAGE, int OCC, bool TL2>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArgs pin) {
   WgradArgs p = pin;
   if (p.batch > 1) {
@@ -970,6 +1230,20 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // Two-level accumulation (rings that run 2 workgroups per CU have the registers for it): the MFMA chain is flushed
+  // into a second accumulator set every 512 pixels, which bounds its rounding noise (it grows ~sqrt(chain length);
+  // a K split of a bs-16 layer is 1200-14400 pixels long).
+  constexpr bool TWO_LEVEL = TL2;
+  constexpr int FLUSH_STEPS = 512 / KS;
+  f32x16 acc2[TWO_LEVEL ? 2 : 1][TWO_LEVEL ? 2 : 1];
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+  }
 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 fa[2], fb[2];
@@ -1021,8 +1295,29 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
     compute(slot);
     pslot = slot;
     slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    if constexpr (TWO_LEVEL) {
+      if ((t & (FLUSH_STEPS - 1)) == FLUSH_STEPS - 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              acc2[i][j][e] += acc[i][j][e];
+              acc[i][j][e] = 0.f;
+            }
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the workgroup has retired
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
+  }
 
   float* out = p.dw + (size_t)ks * p.Co_pad * RS * p.Ci;
   const int ci = ci0 + wn * 64 + 2 * l31;
@@ -1246,9 +1541,25 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     if (BN_ == 128 && tl) LAUNCH_CONV_(BM_, BN_, TR_, RS_, (BN_ == 128));      \
     else LAUNCH_CONV_(BM_, BN_, TR_, RS_, false);                              \
   } while (0)
+#ifndef CONV_DMA_DEFAULT
+#define CONV_DMA_DEFAULT 0
+#endif
+  // SEMSEG_CONV_DMA (read per call): 1 = direct-to-LDS kernel for every eligible conv, 2 = only 3x3, 3 = only 1x1
+  const char* cd_s = getenv("SEMSEG_CONV_DMA");
+  const int cd = cd_s ? atoi(cd_s) : CONV_DMA_DEFAULT;
+  const bool dmac = bl && (cd == 1 || (cd == 2 && RSv == 9) || (cd == 3 && RSv == 1));
+#define LAUNCH_DMA_(BN_, TR_, RS_, TL_) \
+  conv_igemm_dma_kernel<BN_, TR_, RS_, TL_><<<dim3(grid, p.batch), 256, 0, stream>>>(p)
+#define LAUNCH_DMA(BN_, TR_, RS_)                                     \
+  do {                                                                \
+    if (KT > 18) LAUNCH_DMA_(BN_, TR_, RS_, true);                    \
+    else LAUNCH_DMA_(BN_, TR_, RS_, false);                           \
+  } while (0)
 #define LAUNCH_RS(BM_, BN_, TR_)                                   \
   do {                                                             \
-    if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);             \
+    if (dmac && RSv == 9) LAUNCH_DMA(BN_, TR_, 9);                 \
+    else if (dmac) LAUNCH_DMA(BN_, TR_, 1);                        \
+    else if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);        \
     else if (bl) LAUNCH_CONV(BM_, BN_, TR_, 1);                    \
     else LAUNCH_CONV(BM_, BN_, TR_, 0);                            \
   } while (0)
@@ -1263,6 +1574,8 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     if (transposed) LAUNCH_RS(128, 64, true); else LAUNCH_RS(128, 64, false);
   }
 #undef LAUNCH_RS
+#undef LAUNCH_DMA
+#undef LAUNCH_DMA_
 #undef LAUNCH_CONV
 #undef LAUNCH_CONV_
   if (ksplit > 1) {
@@ -1372,8 +1685,8 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
     if (tiles > thr) dma_env = vb;
   }
   const bool dma_ok = (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
-  const int dma = (big && dma_ok && dma_env >= 0 && dma_env <= 5) ? dma_env : 0;
-  static const int occ_of[6] = {3, 2, 3, 2, 5, 5};
+  const int dma = (big && dma_ok && dma_env >= 0 && dma_env <= 7) ? dma_env : 0;
+  static const int occ_of[8] = {3, 2, 3, 2, 5, 5, 2, 2};
   // Fill whole residency rounds (256 CUs x resident workgroups per CU): among the K splits that give at most two
   // rounds, take the one with the best fill (ties: fewer splits = fewer slabs to write and reduce).
   const int ROUND = 256 * occ_of[dma];
@@ -1409,17 +1722,19 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
     else if (mode == 2) conv_wgrad_kernel<TM_, TN_, 2><<<grid, 256, 0, stream>>>(a);  \
     else conv_wgrad_kernel<TM_, TN_, 0><<<grid, 256, 0, stream>>>(a);                 \
   } while (0)
-#define LAUNCH_WGRAD_DMA(KS_, NST_, OCC_)                                                          \
-  do {                                                                                             \
-    if (mode == 1) conv_wgrad_dma_kernel<1, KS_, NST_, OCC_><<<grid, 256, 0, stream>>>(a);         \
-    else if (mode == 2) conv_wgrad_dma_kernel<2, KS_, NST_, OCC_><<<grid, 256, 0, stream>>>(a);    \
-    else conv_wgrad_dma_kernel<0, KS_, NST_, OCC_><<<grid, 256, 0, stream>>>(a);                   \
+#define LAUNCH_WGRAD_DMA(KS_, NST_, OCC_, TL_)                                                          \
+  do {                                                                                                  \
+    if (mode == 1) conv_wgrad_dma_kernel<1, KS_, NST_, OCC_, TL_><<<grid, 256, 0, stream>>>(a);         \
+    else if (mode == 2) conv_wgrad_dma_kernel<2, KS_, NST_, OCC_, TL_><<<grid, 256, 0, stream>>>(a);    \
+    else conv_wgrad_dma_kernel<0, KS_, NST_, OCC_, TL_><<<grid, 256, 0, stream>>>(a);                   \
   } while (0)
-  if (big && dma == 1) LAUNCH_WGRAD_DMA(32, 2, 2);
-  else if (big && dma == 2) LAUNCH_WGRAD_DMA(16, 3, 3);
-  else if (big && dma == 3) LAUNCH_WGRAD_DMA(16, 4, 2);
-  else if (big && dma == 4) LAUNCH_WGRAD_DMA(16, 2, 4);
-  else if (big && dma == 5) LAUNCH_WGRAD_DMA(8, 4, 4);
+  if (big && dma == 1) LAUNCH_WGRAD_DMA(32, 2, 2, false);
+  else if (big && dma == 2) LAUNCH_WGRAD_DMA(16, 3, 3, false);
+  else if (big && dma == 3) LAUNCH_WGRAD_DMA(16, 4, 2, false);
+  else if (big && dma == 4) LAUNCH_WGRAD_DMA(16, 2, 4, false);
+  else if (big && dma == 5) LAUNCH_WGRAD_DMA(8, 4, 4, false);
+  else if (big && dma == 6) LAUNCH_WGRAD_DMA(16, 4, 2, true);    // 3 + two-level accumulation
+  else if (big && dma == 7) LAUNCH_WGRAD_DMA(32, 2, 2, true);    // 1 + two-level accumulation
   else if (big) LAUNCH_WGRAD(128, 128); else LAUNCH_WGRAD(64, 64);
 #undef LAUNCH_WGRAD_DMA
 #undef LAUNCH_WGRAD

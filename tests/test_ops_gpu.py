@@ -49,7 +49,7 @@ WGRAD_BIG_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("case", WGRAD_BIG_CASES)
 def test_wgrad_128_tile_variants(case, variant, report, monkeypatch):
     """Every variant of the 128 x 128 weight-gradient kernel (0 register-staged, 1-5 direct-to-LDS rings with
@@ -77,9 +77,13 @@ def test_wgrad_128_tile_variants(case, variant, report, monkeypatch):
     assert e < 2e-5
 
 
+@pytest.mark.parametrize("conv_dma", [0, 1])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(case, report):
+def test_conv_fwd_dgrad_wgrad(case, conv_dma, report, monkeypatch):
+    """conv_dma = 1: the direct-to-LDS forward / data-gradient kernel (SEMSEG_CONV_DMA) instead of the
+    register-staged one, same cases and bounds."""
     from semseg_amd import ops
+    monkeypatch.setenv("SEMSEG_CONV_DMA", str(conv_dma))
     N, H, W, Ci, Co, k, s, p, d = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = torch.randn(N, Ci, H, W, generator=g)
