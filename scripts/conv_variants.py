@@ -8,6 +8,7 @@ from semseg_amd import ops
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 VARS = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
+VAR = os.environ.get("VAR", "SEMSEG_CONV_DMA")    # e.g. VAR=SEMSEG_CONV_TL to A/B the two-level accumulation rule
 SHAPES = [  # name, H, Ci, Co, k, stride, pad, dil, count(R101)
     ("stem3 64->128 3x3 @237", 237, 64, 128, 3, 1, 1, 1, 1),
     ("l1 conv3 64->256 1x1 @119", 119, 64, 256, 1, 1, 0, 1, 3),
@@ -40,7 +41,7 @@ for name, H, Ci, Co, k, s, p, d, cnt in SHAPES:
            "dgrad": lambda: ops.conv_dgrad(dy, ldy, pk, dx, Ci, N, H, H, s, p, d, scratch=scratch)}
     outs = {}
     for v in VARS:
-        os.environ["SEMSEG_CONV_DMA"] = str(v)
+        os.environ[VAR] = str(v)
         fns["fwd"](); fns["dgrad"]()
         outs[v] = (y.clone(), dx.clone())
     torch.cuda.synchronize()
@@ -48,7 +49,7 @@ for name, H, Ci, Co, k, s, p, d, cnt in SHAPES:
     times = {(v, dd): [] for v in VARS for dd in fns}
     for r in range(ROUNDS):
         for v in VARS:
-            os.environ["SEMSEG_CONV_DMA"] = str(v)
+            os.environ[VAR] = str(v)
             for dd, fn in fns.items():
                 s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s_.record()

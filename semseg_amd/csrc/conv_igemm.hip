@@ -389,8 +389,8 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // Two-level accumulation: the MFMA chain sums sequentially along K, so its rounding noise grows ~sqrt(K)
   // (rms 2.3e-6 at K = 36864, 7x a blocked CPU sum).  Every ~1024 K the chain is flushed into a second
-  // accumulator set, which bounds the chain length.  TL is set by the launcher for K >= 4096 on the
-  // BN = 128 tiles only (240 VGPRs, still occupancy 2); shorter reductions keep the leaner kernel.
+  // accumulator set, which bounds the chain length.  TL is set by the launcher whenever K > 576 (240 VGPRs on the
+  // 128 x 128 tile, still occupancy 2); shorter reductions keep the leaner kernel.
   constexpr bool TWO_LEVEL = CONV_TWO_LEVEL && TL;
   f32x16 acc2[TWO_LEVEL ? MREP : 1][TWO_LEVEL ? NREP : 1];
   if constexpr (TWO_LEVEL) {
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
         step(std::integral_constant<int, 7>{}, c);
         step(std::integral_constant<int, 8>{}, c);
       }
-      // every 4 channel blocks x 9 taps (1152 K) / every 32 channel blocks (1024 K)
-      if (((c - c_begin) & (RS_T == 9 ? 3 : 31)) == (RS_T == 9 ? 3 : 31)) flush();
+      // every 2 channel blocks x 9 taps (576 K) / every 16 channel blocks (512 K)
+      if (((c - c_begin) & (RS_T == 9 ? 1 : 15)) == (RS_T == 9 ? 1 : 15)) flush();
     }
   } else {
   prefetch(kt0);
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
     __syncthreads();
     compute(As, Bs, [&] { if (kt + 1 < KT) prefetch(kt + 1); });
     __syncthreads();
-    if (((kt - kt0) & 31) == 31) flush();
+    if (((kt - kt0) & 15) == 15) flush();
   }
 #endif
   }  // RS_T == 0
@@ -1533,12 +1533,17 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   const size_t x_bytes = (size_t)a.N * a.Hin * a.Win * a.ldx * 4, w_bytes = (size_t)p.tiles_n * BN * KT * BK * 4;
   const bool bl = CONV_BUFLOAD && !big && (RSv == 1 || RSv == 9) && (p.kt_per % RSv == 0) &&
                   x_bytes < 0x7FFF0000ull && w_bytes < 0x7FFF0000ull;
-  const bool tl = BN == 128 && KT >= 128;      // two-level accumulation for K >= 4096 (see the kernel)
+  // Two-level accumulation whenever the reduction is longer than one flush interval (K > 576).  Round 1 used it for
+  // K >= 4096 only; the in-situ backward test of round 2 showed single chains of K = 1152 ... 2304 (aux.0 /
+  // layer0.6 data gradients) at 2.7-2.9x the rounding noise (rms) of the CPU's blocked sums, 6x in the maximum.
+  // SEMSEG_CONV_TL=0 restores the round-1 rule (A/B only).
+  const char* tl_s = getenv("SEMSEG_CONV_TL");
+  const bool tl = (tl_s && tl_s[0] == '0') ? (BN == 128 && KT >= 128) : KT > 18;
 #define LAUNCH_CONV_(BM_, BN_, TR_, RS_, TL_) \
   conv_igemm_kernel<BM_, BN_, TR_, RS_, TL_><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p)
 #define LAUNCH_CONV(BM_, BN_, TR_, RS_)                                        \
   do {                                                                         \
-    if (BN_ == 128 && tl) LAUNCH_CONV_(BM_, BN_, TR_, RS_, (BN_ == 128));      \
+    if (tl) LAUNCH_CONV_(BM_, BN_, TR_, RS_, true);                            \
     else LAUNCH_CONV_(BM_, BN_, TR_, RS_, false);                              \
   } while (0)
 #ifndef CONV_DMA_DEFAULT
@@ -1552,7 +1557,7 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   conv_igemm_dma_kernel<BN_, TR_, RS_, TL_><<<dim3(grid, p.batch), 256, 0, stream>>>(p)
 #define LAUNCH_DMA(BN_, TR_, RS_)                                     \
   do {                                                                \
-    if (KT > 18) LAUNCH_DMA_(BN_, TR_, RS_, true);                    \
+    if (tl) LAUNCH_DMA_(BN_, TR_, RS_, true);                         \
     else LAUNCH_DMA_(BN_, TR_, RS_, false);                           \
   } while (0)
 #define LAUNCH_RS(BM_, BN_, TR_)                                   \
@@ -1673,7 +1678,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   // the step, where the weight gradients share the chip with the main stream, the 2-workgroup-per-CU ring (3) wins
   // for every layer (207.9 ms vs 210.1 for "1:3:32" and 212.2 for 2).
 #ifndef WGRAD_DMA_POLICY
-#define WGRAD_DMA_POLICY "3"
+#define WGRAD_DMA_POLICY "6"
 #endif
   const char* dma_s = getenv("SEMSEG_WGRAD_DMA");
   if (!dma_s) dma_s = WGRAD_DMA_POLICY;
