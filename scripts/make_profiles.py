@@ -69,5 +69,19 @@ with open(os.path.join(ROOT, "profiles", tag + "_bench_family_stats.csv"), "w") 
     fo.write("family,calls,total_ms,avg_us\n")
     for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         fo.write('"%s",%d,%.3f,%.2f\n' % (k, c, t / 1e6, t / c / 1e3))
+# serialized run (SEMSEG_SIDE_WGRAD=0 SEMSEG_HIPRI_MAIN=0): the durations the bench line's roofline is quoted on
+sp = os.path.join(g, tag + "_serial", "bench_kernel_stats.csv")
+if os.path.exists(sp):
+    shutil.copy(sp, os.path.join(ROOT, "profiles", tag + "_serial_kernel_stats.csv"))
+    fs = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(sp)):
+        k = family(short(r['Name'] + "("))
+        fs[k][0] += int(r['Calls']); fs[k][1] += float(r['TotalDurationNs'])
+    with open(os.path.join(ROOT, "profiles", tag + "_serial_family_stats.csv"), "w") as fo:
+        fo.write("family,calls,total_ms,avg_us\n")
+        for k, (c, t) in sorted(fs.items(), key=lambda kv: -kv[1][1]):
+            fo.write('"%s",%d,%.3f,%.2f\n' % (k, c, t / 1e6, t / c / 1e3))
+    w2 = fs.get('conv_wgrad_dma_kernel<128x128>'); r2 = fs.get('wgrad_reduce_unpack_kernel')
+    if w2: print("serialized rocprof: 128x128 weight-gradient kernel avg %.1f us over %d launches (+ reduce %.1f us)" % (w2[1] / w2[0] / 1e3, w2[0], r2[1] / r2[0] / 1e3 if r2 else 0))
 wg = fam.get('conv_wgrad_dma_kernel<128x128>') or fam.get('conv_wgrad_kernel<128, 128>'); ru = fam.get('wgrad_reduce_unpack_kernel')
 if wg: print("rocprof family 128x128 weight-gradient kernel: avg %.1f us over %d launches (reduce kernel avg %.1f us)" % (wg[1] / wg[0] / 1e3, wg[0], ru[1] / ru[0] / 1e3 if ru else 0))

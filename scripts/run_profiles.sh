@@ -7,6 +7,11 @@ out=gpurun_out
 rm -rf $out/${tag}_stats $out/${tag}_fetch $out/${tag}_write $out/${tag}_mfma
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o bench -- python bench.py > $out/bench_${tag}_n1.log 2>&1
 grep "^{\"metric\"" $out/bench_${tag}_n1.log | tail -1 > $out/bench_${tag}_n1.json
+# the same command with every kernel on one stream: per-kernel durations without the side-stream concurrency (what the
+# bench line's roofline / kernel_families are measured on)
+rm -rf $out/${tag}_serial
+SEMSEG_SIDE_WGRAD=0 SEMSEG_HIPRI_MAIN=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_serial -o bench -- python bench.py --no-cpu-baseline > $out/bench_${tag}_serial.log 2>&1
+f=$(find $out/${tag}_serial -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && [ "$f" != "$out/${tag}_serial/bench_kernel_stats.csv" ] && cp "$f" $out/${tag}_serial/bench_kernel_stats.csv
 B="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing"
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch -o pmc -- $B > $out/${tag}_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_write -o pmc -- $B > $out/${tag}_write.log 2>&1
