@@ -14,7 +14,9 @@ ARCH = sys.argv[3] if len(sys.argv) > 3 else "psp"
 SIZE = 473 if ARCH == "psp" else 465
 # "policy/side/hipri/convdma": policy = SEMSEG_WGRAD_DMA value (a variant number or "small:big:tile-threshold"),
 # convdma = SEMSEG_CONV_DMA (forward / data-gradient kernel: 0 register-staged, 1 direct-to-LDS, 2 only 3x3, 3 only 1x1)
-CONFIGS = [(c.split("/")[0], int(c.split("/")[1]), int(c.split("/")[2]), int(c.split("/")[3])) for c in
+# optional 5th field: extra environment "KEY=VAL+KEY=VAL" read per launch by the library (e.g. SEMSEG_CONV_TL=0)
+CONFIGS = [(c.split("/")[0], int(c.split("/")[1]), int(c.split("/")[2]), int(c.split("/")[3]),
+            c.split("/")[4] if len(c.split("/")) > 4 else "") for c in
            os.environ.get("CONFIGS", "0/0/0/0,3/1/1/0,3/1/1/1,6/1/1/0,6/1/1/1,7/1/1/1,3/1/1/2,3/1/1/3,6/0/0/1").split(",")]
 torch.manual_seed(0)
 if ARCH == "psp":
@@ -33,7 +35,9 @@ eng = next(iter(tr.engines.values()))
 res = {c: [] for c in CONFIGS}
 for r in range(ROUNDS):
     for c in CONFIGS:
-        dma, side, hipri, cdma = c
+        dma, side, hipri, cdma, extra = c
+        for kv in [e for e in extra.split("+") if e]:
+            os.environ[kv.split("=")[0]] = kv.split("=")[1]
         os.environ["SEMSEG_WGRAD_DMA"] = str(dma)
         os.environ["SEMSEG_CONV_DMA"] = str(cdma)
         eng.side_all, eng.hipri_main = bool(side), bool(hipri)
@@ -46,5 +50,5 @@ for r in range(ROUNDS):
         res[c].append((time.time() - t0) / 5 * 1e3)
 print("%s batch %d: ms per step (min over %d rounds / all)" % (ARCH, B, ROUNDS))
 for c in CONFIGS:
-    print("  wgrad %-8s side_all %d hipri %d conv_dma %d : %8.2f   %s" % (c + (min(res[c]), " ".join("%.2f" % v for v in res[c]))))
+    print("  wgrad %-8s side_all %d hipri %d conv_dma %d %-18s: %8.2f   %s" % (c + (min(res[c]), " ".join("%.2f" % v for v in res[c]))))
 print("final loss", float(ml.item()))

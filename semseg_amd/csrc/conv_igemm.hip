@@ -1538,7 +1538,11 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   // layer0.6 data gradients) at 2.7-2.9x the rounding noise (rms) of the CPU's blocked sums, 6x in the maximum.
   // SEMSEG_CONV_TL=0 restores the round-1 rule (A/B only).
   const char* tl_s = getenv("SEMSEG_CONV_TL");
-  const bool tl = (tl_s && tl_s[0] == '0') ? (BN == 128 && KT >= 128) : KT > 18;
+  // what counts is the chain one workgroup accumulates: the whole reduction for unsplit tiles, one K slice when
+  // every tile is split (small per-GPU batch: slices are <= 18 K-steps there and the leaner kernel is 5 % faster
+  // over the whole bs-2 step)
+  const int chain = p.full_tiles > 0 ? KT : p.kt_per;
+  const bool tl = (tl_s && tl_s[0] == '0') ? (BN == 128 && KT >= 128) : chain > 18;
 #define LAUNCH_CONV_(BM_, BN_, TR_, RS_, TL_) \
   conv_igemm_kernel<BM_, BN_, TR_, RS_, TL_><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p)
 #define LAUNCH_CONV(BM_, BN_, TR_, RS_)                                        \
