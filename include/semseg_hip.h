@@ -64,6 +64,17 @@ int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
                       int pad, int dil, const float* add, int ldadd, int tile_n, float* scratch,
                       size_t scratch_floats, hipStream_t stream);
+/* Data gradient + the BatchNorm-backward reduction (torch batch_norm backward for model/resnet.py:76-92) of the
+ * layer(s) that PRODUCED this conv's input, in one kernel: dx = g = (dgrad (+ add)) * (act > 0), and
+ * sums{0,1}[nslot][2*Ci] += {sum g, sum g * (y - mean) * invstd} in fp64 (slot replicas as in semseg_channel_stats).
+ * Valid only when this data gradient is the last contribution to that activation's gradient.  act may be null (no
+ * ReLU); bn_count 2 = bn3 + downsample BN sharing g.  Ci % 4 == 0, every ld % 4 == 0. */
+int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N, int H,
+                               int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad, int dil,
+                               const float* add, int ldadd, int tile_n, int bn_count, const float* act, int ldact,
+                               const float* y0, int ldy0, const float* mean0, const float* invstd0, double* sums0,
+                               const float* y1, int ldy1, const float* mean1, const float* invstd1, double* sums1,
+                               int nslot, float* scratch, size_t scratch_floats, hipStream_t stream);
 /* dw_oihw[Co][Ci][R][S] (=|+=) sum over pixels; scratch holds the split-K partial slabs
  * (>= semseg_conv_wgrad_scratch_floats(...) floats; more slabs => more K parallelism AND shorter fp32
  * accumulation chains: with a single slab the whole pixel reduction is one chain and its rounding noise

@@ -38,6 +38,8 @@ for r in range(ROUNDS):
         dma, side, hipri, cdma, extra = c
         for kv in [e for e in extra.split("+") if e]:
             os.environ[kv.split("=")[0]] = kv.split("=")[1]
+            if kv.split("=")[0] == "NSIDE":          # number of weight-gradient streams (Engine.n_side)
+                eng.n_side = int(kv.split("=")[1])
         os.environ["SEMSEG_WGRAD_DMA"] = str(dma)
         os.environ["SEMSEG_CONV_DMA"] = str(cdma)
         eng.side_all, eng.hipri_main = bool(side), bool(hipri)

@@ -114,12 +114,24 @@ struct ConvArgs {
   // operand advances by its batch stride (floats).  batch == 1: plain convolution.
   int batch;
   long long x_bs, w_bs, y_bs, add_bs;
+  // Fused BatchNorm-backward reduction (data gradient only; bnr_n = 0: off).  The tile this kernel produces is the
+  // COMPLETE gradient dout of a BatchNorm(+ReLU) output, so the epilogue does what bn_bwd_reduce would do in a
+  // separate pass over HBM: g = dout * (act > 0) is what gets stored, and sum g, sum g * xhat are accumulated in fp64
+  // for up to two BatchNorm layers that share g (bn3 + the downsample BN of a bottleneck, model/resnet.py:88-92).
+  int bnr_n;
+  const float* bnr_mask;          // post-ReLU activation [M][bnr_ldm] (nullptr: no ReLU)
+  int bnr_ldm;
+  const float* bnr_y[2];          // pre-BN tensors [M][bnr_ldy]
+  int bnr_ldy[2];
+  const float* bnr_mean[2];
+  const float* bnr_invstd[2];
+  double* bnr_sums[2];            // [stats_nslot][2 * Nout]
 };
 
 // ---- epilogue shared by the register-staged and the direct-to-LDS kernels ----
 template <int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2][BN / 64], float* smem, bool split,
-                                              int ks, int m0, int n0, int tile_m) {
+                                              int ks, int m0, int n0, int tile_m, double* red2) {
   constexpr int NT = BM * 2;
   constexpr int MREP = 2, NREP = BN / 64;
   const int tid = threadIdx.x;
@@ -139,6 +151,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
   const bool wide = split || ((p.ldy & 3) == 0 && p.ldy >= Nout4 && (!p.add || (p.ldadd & 3) == 0));
   float* wl = smem + wave * (64 * LDK);              // this wave's slab (needs >= NT/64 * 64 * LDK floats)
   double* red = reinterpret_cast<double*>(smem);     // [BM/64 (wm)][BN][2], used after the stores
+  const bool bnr = !split && p.bnr_n > 0;            // fused BatchNorm-backward reduction (wide stores only)
   double st1[NREP], st2[NREP];
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
@@ -149,6 +162,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
     const float sv = (!split && p.scale && cok) ? p.scale[col] : 1.f;
     const bool relu = !split && p.relu;
     double s1 = 0.0, s2 = 0.0;
+    f32x4 bmu[2], bis[2];
+    double bs[2][8];
+    if (bnr) {
+      const int cb = n0 + wn * (BN / 2) + j * 32 + (lane & 7) * 4;      // this lane's 4 columns in the stores below
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bs[b][k] = 0.0;
+        if (b < p.bnr_n && cb < Nout4) {
+          bmu[b] = *reinterpret_cast<const f32x4*>(p.bnr_mean[b] + cb);
+          bis[b] = *reinterpret_cast<const f32x4*>(p.bnr_invstd[b] + cb);
+        } else {
+          bmu[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+          bis[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
     if (wide) {
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
@@ -177,8 +207,41 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
           }
+          if (bnr) {
+            if (p.bnr_mask) {
+              const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.bnr_mask + (size_t)m * p.bnr_ldm + cg);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = a4[k] > 0.f ? v[k] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              if (b < p.bnr_n) {
+                const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.bnr_y[b] + (size_t)m * p.bnr_ldy[b] + cg);
+                const f32x4 xh = (y4 - bmu[b]) * bis[b];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  bs[b][k] += (double)v[k];
+                  bs[b][4 + k] += (double)v[k] * (double)xh[k];
+                }
+              }
+          }
           *reinterpret_cast<f32x4*>(dst + (size_t)(m - mrow0) * ldd + cg) = v;
         }
+      }
+      if (bnr) {
+        // lanes with equal (lane & 7) hold the same 4 columns for different rows: fold them, lanes 0-7 keep the totals
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (b < p.bnr_n) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              double t = bs[b][k];
+              t += shfl_xor_f64(t, 8);
+              t += shfl_xor_f64(t, 16);
+              t += shfl_xor_f64(t, 32);
+              if (lane < 8) red2[((b * (BM / 64) + wm) * BN + wn * (BN / 2) + j * 32 + lane * 4 + (k & 3)) * 2 + (k >> 2)] = t;
+            }
+          }
       }
     } else {
 #pragma unroll
@@ -228,6 +291,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
       }
     }
   }
+  if (bnr) {
+    __syncthreads();   // red2 holds every wave's column sums: [bn][wm][BN][2]
+    if (tid < BN) {
+      const int col = n0 + tid;
+      if (col < p.Nout) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (b < p.bnr_n) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < BM / 64; ++r) {
+              s1 += red2[((b * (BM / 64) + r) * BN + tid) * 2 + 0];
+              s2 += red2[((b * (BM / 64) + r) * BN + tid) * 2 + 1];
+            }
+            double* st = p.bnr_sums[b] + (size_t)(tile_m % p.stats_nslot) * 2 * p.Nout;
+            atomic_add_f64(&st[col], s1);
+            atomic_add_f64(&st[p.Nout + col], s2);
+          }
+      }
+    }
+  }
 }
 
 // RS_T == 0: generic tap walk with global loads.  RS_T == 1 / 9 (1x1 / 3x3): the tap loop is unrolled
@@ -254,7 +338,9 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
 #define CONV_LDSPAD 0
 #endif
   constexpr int EPI = (NT / 64) * 64 * LDK;  // per-wave transposition slabs of the epilogue
-  constexpr int SMEM_F = ((CONV_DBUF ? 2 : 1) * STAGE > EPI ? (CONV_DBUF ? 2 : 1) * STAGE : EPI) + CONV_LDSPAD;
+  constexpr int SMEM_BASE = ((CONV_DBUF ? 2 : 1) * STAGE > EPI ? (CONV_DBUF ? 2 : 1) * STAGE : EPI) + CONV_LDSPAD;
+  constexpr int RED2_F = TR ? 2 * (BM / 64) * BN * 2 * 2 : 0;   // fp64 column sums of the fused BatchNorm-backward reduction
+  constexpr int SMEM_F = SMEM_BASE + RED2_F;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
   float* As = smem;
   float* Bs = smem + BM * LDK;
@@ -586,7 +672,7 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
         for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
   }
 
-  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m);
+  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m, reinterpret_cast<double*>(smem + SMEM_BASE));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -825,18 +911,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const ConvArgs p
   // epilogue's transposition slabs once every wave has left the K loop
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m);
+  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m, nullptr);
 }
 
 // Split-K epilogue: y = sum_ks part[ks] (+bias) (+add); optional fp64 channel statistics.
 // Thread = one float4 of channels, rows strided over the grid (same tiling as the BN reductions).
+struct BnrArgs {   // fused BatchNorm-backward reduction (see ConvArgs::bnr_*); pointers already at the first row handled
+  int n;
+  const float* mask; int ldm;
+  const float* y[2]; int ldy[2];
+  const float* mean[2]; const float* invstd[2];
+  double* sums[2];
+};
+
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part,
                                                               int ksplit, int ldpart, float* y,
                                                               int ldy, const float* bias,
                                                               const float* scale, int relu,
                                                               const float* add, int ldadd,
                                                               double* stats, int nslot, int M,
-                                                              int Nout, int tpr, int rpb) {
+                                                              int Nout, int tpr, int rpb, const BnrArgs bn) {
   __shared__ double sred[256 * 8];
   const int CV = (Nout + 3) >> 2;
   const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
@@ -844,6 +938,16 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   const bool active = c4 < CV;
   const int c = c4 * 4;
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double w2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // second BatchNorm layer of the fused reduction
+  f32x4 bmu[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, bis[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (active && bn.n > 0) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      if (b < bn.n) {
+        bmu[b] = *reinterpret_cast<const f32x4*>(bn.mean[b] + c);
+        bis[b] = *reinterpret_cast<const f32x4*>(bn.invstd[b] + c);
+      }
+  }
   if (active) {
     f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {1.f, 1.f, 1.f, 1.f};
     if (bias) {
@@ -876,11 +980,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
         const int m = mb + u * step;
         if (m < M) {
           f32x4 r = a[u] * sv + bv;
+          if (bn.n == 0) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const double d = (double)r[k];
-            v[k] += d;
-            v[4 + k] += d * d;
+            for (int k = 0; k < 4; ++k) {
+              const double d = (double)r[k];
+              v[k] += d;
+              v[4 + k] += d * d;
+            }
           }
           if (add) {
 #pragma unroll
@@ -891,10 +997,61 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k) r[k] = fmaxf(r[k], 0.f);
           }
+          if (bn.n > 0) {
+            if (bn.mask) {
+              const f32x4 a4 = *reinterpret_cast<const f32x4*>(bn.mask + (size_t)m * bn.ldm + c);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) r[k] = a4[k] > 0.f ? r[k] : 0.f;
+            }
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(bn.y[0] + (size_t)m * bn.ldy[0] + c);
+            const f32x4 xh0 = (y0 - bmu[0]) * bis[0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[k] += (double)r[k];
+              v[4 + k] += (double)r[k] * (double)xh0[k];
+            }
+            if (bn.n > 1) {
+              const f32x4 y1 = *reinterpret_cast<const f32x4*>(bn.y[1] + (size_t)m * bn.ldy[1] + c);
+              const f32x4 xh1 = (y1 - bmu[1]) * bis[1];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                w2[k] += (double)r[k];
+                w2[4 + k] += (double)r[k] * (double)xh1[k];
+              }
+            }
+          }
           *reinterpret_cast<f32x4*>(y + (size_t)m * ldy + c) = r;
         }
       }
     }
+  }
+  if (bn.n > 0) {
+    // same block reduction + slot as the statistics path, once per BatchNorm layer
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      if (b < bn.n) {
+        double* acc8 = b == 0 ? v : w2;
+        if (rpb > 1) {
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sred[(tr * tpr + tc) * 8 + k] = acc8[k];
+          __syncthreads();
+          if (tr == 0)
+            for (int r = 1; r < rpb; ++r)
+#pragma unroll
+              for (int k = 0; k < 8; ++k) acc8[k] += sred[(r * tpr + tc) * 8 + k];
+        }
+        if (tr == 0 && active) {
+          double* st = bn.sums[b] + (size_t)((blockIdx.x + blockIdx.y) % nslot) * 2 * Nout;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (c + k < Nout) {
+              atomic_add_f64(&st[c + k], acc8[k]);
+              atomic_add_f64(&st[Nout + c + k], acc8[4 + k]);
+            }
+        }
+      }
+    return;
   }
   if (stats) {
     if (rpb > 1) {
@@ -1556,7 +1713,7 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   // SEMSEG_CONV_DMA (read per call): 1 = direct-to-LDS kernel for every eligible conv, 2 = only 3x3, 3 = only 1x1
   const char* cd_s = getenv("SEMSEG_CONV_DMA");
   const int cd = cd_s ? atoi(cd_s) : CONV_DMA_DEFAULT;
-  const bool dmac = bl && (cd == 1 || (cd == 2 && RSv == 9) || (cd == 3 && RSv == 1));
+  const bool dmac = bl && a.bnr_n == 0 && (cd == 1 || (cd == 2 && RSv == 9) || (cd == 3 && RSv == 1));
 #define LAUNCH_DMA_(BN_, TR_, RS_, TL_) \
   conv_igemm_dma_kernel<BN_, TR_, RS_, TL_><<<dim3(grid, p.batch), 256, 0, stream>>>(p)
 #define LAUNCH_DMA(BN_, TR_, RS_)                                     \
@@ -1597,10 +1754,22 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     int cap = 512 / gx;  // more blocks only add fp64 statistic atomics (1024 / 2048: forward +11 / +16 % at bs 2)
     if (cap < 1) cap = 1;
     if (gy > cap) gy = cap;
+    BnrArgs bn;
+    bn.n = a.bnr_n;
+    bn.mask = (a.bnr_n && a.bnr_mask) ? a.bnr_mask + (size_t)p.tail_m0 * a.bnr_ldm : nullptr;
+    bn.ldm = a.bnr_ldm;
+    for (int b = 0; b < 2; ++b) {
+      const bool on = b < a.bnr_n;
+      bn.y[b] = on ? a.bnr_y[b] + (size_t)p.tail_m0 * a.bnr_ldy[b] : nullptr;
+      bn.ldy[b] = on ? a.bnr_ldy[b] : 0;
+      bn.mean[b] = on ? a.bnr_mean[b] : nullptr;
+      bn.invstd[b] = on ? a.bnr_invstd[b] : nullptr;
+      bn.sums[b] = on ? a.bnr_sums[b] : nullptr;
+    }
     splitk_epilogue_kernel<<<dim3(gx, gy), 256, 0, stream>>>(
         scratch, ksplit, p.ldpart, a.y + (size_t)p.tail_m0 * a.ldy, a.ldy, a.bias, a.scale, a.relu,
         a.add ? a.add + (size_t)p.tail_m0 * a.ldadd : nullptr, a.ldadd, a.stats, a.stats_nslot, Mt, a.Nout,
-        tpr, rpb);
+        tpr, rpb, bn);
   }
   return semseg_launch_status();
 }
@@ -1618,13 +1787,13 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
   a.N = N; a.Hin = H; a.Win = W; a.Hout = Ho; a.Wout = Wo;
   a.Kc = Ci; a.Nout = Co; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * Ho * Wo; a.tiles_n = 0; a.stats_nslot = stats_nslot > 0 ? stats_nslot : 1;
-  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0;
+  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0; a.bnr_n = 0; a.bnr_mask = nullptr;
   return conv_launch(false, a, tile_n, scratch, scratch_floats, stream);
 }
 
-int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
+static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
-                      int pad, int dil, const float* add, int ldadd, int tile_n, float* scratch,
+                      int pad, int dil, const float* add, int ldadd, int tile_n, const ConvArgs* bnr, float* scratch,
                       size_t scratch_floats, hipStream_t stream) {
   if (!dy || !w_dgrad || !dx || (lddy & 3) || (tile_n != 64 && tile_n != 128)) return SEMSEG_EINVAL;
   const int Kc = (Co + 31) / 32 * 32;
@@ -1635,8 +1804,47 @@ int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx
   a.N = N; a.Hin = Ho; a.Win = Wo; a.Hout = H; a.Wout = W;
   a.Kc = Kc; a.Nout = Ci; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * H * W; a.tiles_n = 0; a.stats_nslot = 1;
-  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0;
+  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0; a.bnr_n = 0; a.bnr_mask = nullptr;
+  if (bnr) {
+    a.bnr_n = bnr->bnr_n; a.bnr_mask = bnr->bnr_mask; a.bnr_ldm = bnr->bnr_ldm; a.stats_nslot = bnr->stats_nslot;
+    for (int b = 0; b < 2; ++b) {
+      a.bnr_y[b] = bnr->bnr_y[b]; a.bnr_ldy[b] = bnr->bnr_ldy[b]; a.bnr_mean[b] = bnr->bnr_mean[b];
+      a.bnr_invstd[b] = bnr->bnr_invstd[b]; a.bnr_sums[b] = bnr->bnr_sums[b];
+    }
+  }
   return conv_launch(true, a, tile_n, scratch, scratch_floats, stream);
+}
+
+int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
+                      int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                      int pad, int dil, const float* add, int ldadd, int tile_n, float* scratch,
+                      size_t scratch_floats, hipStream_t stream) {
+  return dgrad_impl(dy, lddy, w_dgrad, dx, lddx, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, add, ldadd, tile_n,
+                    nullptr, scratch, scratch_floats, stream);
+}
+
+// Data gradient + the BatchNorm-backward reduction of the layer(s) that PRODUCED this conv's input, in one kernel:
+// dx receives g = (dgrad (+ add)) * (act > 0) and sums{0,1}[slot][2*Ci] += {sum g, sum g * (y - mean) * invstd} (fp64).
+// Replaces the separate pass of semseg_bn_bwd_reduce (model/resnet.py:76-92 backward); only valid when this data
+// gradient is the LAST contribution to that activation's gradient.  act may be null (no ReLU).
+int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N, int H,
+                               int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad, int dil,
+                               const float* add, int ldadd, int tile_n, int bn_count, const float* act, int ldact,
+                               const float* y0, int ldy0, const float* mean0, const float* invstd0, double* sums0,
+                               const float* y1, int ldy1, const float* mean1, const float* invstd1, double* sums1,
+                               int nslot, float* scratch, size_t scratch_floats, hipStream_t stream) {
+  if (bn_count < 1 || bn_count > 2 || !y0 || !mean0 || !invstd0 || !sums0 || nslot < 1) return SEMSEG_EINVAL;
+  if (bn_count == 2 && (!y1 || !mean1 || !invstd1 || !sums1)) return SEMSEG_EINVAL;
+  // the fused path lives in the 16-byte store phase of the epilogue: everything 4-float aligned, channels % 4 == 0
+  if ((Ci & 3) || (lddx & 3) || lddx < Ci || (ldy0 & 3) || (act && (ldact & 3)) || (add && (ldadd & 3)) ||
+      (bn_count == 2 && (ldy1 & 3)))
+    return SEMSEG_EINVAL;
+  ConvArgs b;
+  b.bnr_n = bn_count; b.bnr_mask = act; b.bnr_ldm = ldact; b.stats_nslot = nslot;
+  b.bnr_y[0] = y0; b.bnr_ldy[0] = ldy0; b.bnr_mean[0] = mean0; b.bnr_invstd[0] = invstd0; b.bnr_sums[0] = sums0;
+  b.bnr_y[1] = y1; b.bnr_ldy[1] = ldy1; b.bnr_mean[1] = mean1; b.bnr_invstd[1] = invstd1; b.bnr_sums[1] = sums1;
+  return dgrad_impl(dy, lddy, w_dgrad, dx, lddx, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, add, ldadd, tile_n, &b,
+                    scratch, scratch_floats, stream);
 }
 
 static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
@@ -1698,7 +1906,11 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   static const int occ_of[8] = {3, 2, 3, 2, 5, 5, 2, 2};
   // Fill whole residency rounds (256 CUs x resident workgroups per CU): among the K splits that give at most two
   // rounds, take the one with the best fill (ties: fewer splits = fewer slabs to write and reduce).
-  const int ROUND = 256 * occ_of[dma];
+  // SEMSEG_WGRAD_FILL = n (read per call): aim at 1/n of a residency round — the engine runs n weight gradients
+  // side by side on n streams, each with a proportionally smaller K split (longer K loops, fewer slabs)
+  const char* fill_s = getenv("SEMSEG_WGRAD_FILL");
+  const int fill = fill_s ? (atoi(fill_s) > 0 ? atoi(fill_s) : 1) : 1;
+  const int ROUND = 256 * occ_of[dma] / fill;
   const int wg1 = tiles * batch;     // workgroups per K slice
   int ksplit = 1;
   {
@@ -1774,7 +1986,7 @@ int semseg_gemm_rows_batched(const float* a, int lda, long long a_bs, const floa
   g.N = 1; g.Hin = M; g.Win = 1; g.Hout = M; g.Wout = 1;
   g.Kc = K; g.Nout = Nout; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.dil = 1;
   g.M = M; g.tiles_n = 0; g.stats_nslot = 1;
-  g.batch = batch; g.x_bs = a_bs; g.w_bs = bt_bs; g.y_bs = c_bs; g.add_bs = 0;
+  g.batch = batch; g.x_bs = a_bs; g.w_bs = bt_bs; g.y_bs = c_bs; g.add_bs = 0; g.bnr_n = 0; g.bnr_mask = nullptr;
   return conv_launch(false, g, Nout >= 128 ? 128 : 64, nullptr, 0, stream);
 }
 

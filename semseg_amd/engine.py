@@ -76,13 +76,20 @@ class TapeOp:
 
 class Act:
     """NHWC activation view: `data` starts at the first valid channel; `ld` = channel stride."""
-    __slots__ = ("data", "N", "H", "W", "C", "ld", "grad", "ginit", "name")
+    __slots__ = ("data", "N", "H", "W", "C", "ld", "grad", "ginit", "name", "bnsrc", "fuse_ok", "pending", "bn_reduced")
 
     def __init__(self, data, N, H, W, C, ld, name=""):
         self.data, self.N, self.H, self.W, self.C, self.ld = data, N, H, W, C, ld
         self.grad = None
         self.ginit = False
         self.name = name
+        # fused BatchNorm-backward reduction (Engine._conv_bwd): which BatchNorm(s) produced this activation, whether
+        # all of its consumers are convs / residual adds (set by Engine.bottleneck), how many gradient contributions
+        # are still outstanding in backward, and whether the last one already did the reduction
+        self.bnsrc = None
+        self.fuse_ok = False
+        self.pending = 0
+        self.bn_reduced = False
 
     @property
     def M(self):
@@ -160,9 +167,13 @@ class Engine:
         # The dependent chain of backward (data gradients + BatchNorm) runs on a high-priority stream so that it wins
         # the dispatch race against the weight gradients queued on the side stream.
         self.hipri_main = os.environ.get("SEMSEG_HIPRI_MAIN", "1") == "1"
+        # number of weight-gradient streams used round-robin (each with its own split-K scratch)
+        self.n_side = int(os.environ.get("SEMSEG_SIDE_STREAMS", "1"))
+        # fold bn_bwd_reduce into the epilogue of the data gradient that completes a BatchNorm output's gradient
+        self.fuse_bnr = os.environ.get("SEMSEG_FUSE_BNR", "1") == "1"
+        self._sides, self._scr2s, self._side_rr = [], [], 0
         self._hi = None
         self._side = None
-        self._scr2 = None
         self._side_used = False
         self._mod_ids = tuple(id(m) for m in model.modules())
         self._labels_checked = False
@@ -325,6 +336,8 @@ class Engine:
                          nslot=ops.NSLOT, scratch=self.scratch())
         self._t1(ev)
         if self.training:
+            if x.fuse_ok:
+                x.pending += 1
             self.push("conv", lambda: self._conv_bwd(x, out, cl, m), x=x, y=out, cl=cl, m=m)
         return out
 
@@ -359,30 +372,46 @@ class Engine:
         # the end of backward().
         side = self.side_wgrad and (self.side_all or y.M * cl.Co < 512 * 128 * 128)
         if side:
-            st = self._side_stream()
+            st, scr = self._side_stream()
             st.wait_stream(torch.cuda.current_stream())
             self._side_used = True      # before the block: _wgrad may hand a gradient bucket to the communicator
             with torch.cuda.stream(st):
-                self._wgrad(x, y, cl, m, self._scratch2())
+                self._wgrad(x, y, cl, m, scr)
         else:
             self._wgrad(x, y, cl, m, self.scratch())
         if x.name != "input":
             gx = self.grad_of(x)
+            # This data gradient completes x.grad when it is the last outstanding contribution; if x is a
+            # BatchNorm(+ReLU) output whose consumers are all convs / residual adds, the BatchNorm-backward reduction
+            # (mask + fp64 sum g, sum g*xhat) rides in its epilogue instead of a separate pass over HBM.
+            last = x.fuse_ok and x.pending == 1
+            if x.fuse_ok:
+                x.pending -= 1
+            bs = x.bnsrc
+            fuse = (self.fuse_bnr and last and bs is not None and x.C % 4 == 0 and x.ld % 4 == 0 and
+                    all(yk.ld % 4 == 0 for yk, _ in bs["bns"]))
             ev = self._t0("conv_igemm_kernel<128,%d,true,%d>(+splitk_epilogue)" % (cl.pk.tile_dgrad, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), flops)
-            ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                           add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
+            if fuse:
+                ops.conv_dgrad_bnreduce(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                                        x.data if bs["relu"] else None, x.ld,
+                                        [(yk.data, yk.ld, blk.mean, blk.invstd, blk.sums) for yk, blk in bs["bns"]],
+                                        ops.NSLOT, add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
+                x.bn_reduced = True
+            else:
+                ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                               add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
             self._t1(ev)
             x.ginit = True
 
     def _side_stream(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
-
-    def _scratch2(self):
-        if self._scr2 is None:
-            self._scr2 = torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device)
-        return self._scr2
+        """Next weight-gradient stream (round-robin over n_side) and its private split-K scratch."""
+        while len(self._sides) < max(1, self.n_side):
+            self._sides.append(torch.cuda.Stream(device=self.device))
+            self._scr2s.append(torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device))
+        i = self._side_rr % max(1, self.n_side)
+        self._side_rr += 1
+        self._side = self._sides[0]
+        return self._sides[i], self._scr2s[i]
 
     def scratch(self):
         """256 MB arena for split-K partial slabs (conv fwd/dgrad at small batch, every wgrad)."""
@@ -419,13 +448,12 @@ class Engine:
         collective is only ordered after the stream that is current when it is issued.  Make that stream
         wait for everything the other one has enqueued so far; call this right before a gradient bucket
         is handed to the communicator (the call may come from either stream)."""
-        if self._side is None or not self._side_used:
+        if not self._sides or not self._side_used:
             return
         cur = torch.cuda.current_stream()
-        if cur == self._side:
-            cur.wait_stream(self._main)
-        else:
-            cur.wait_stream(self._side)
+        for st in self._sides + [self._main]:
+            if st != cur:
+                cur.wait_stream(st)
 
     def _sync(self, t):
         if (self.sync_bn or self.force_sync_bn) and self.dist_on:
@@ -474,6 +502,10 @@ class Engine:
                      res=None if res is None else res.data, ldres=0 if res is None else res.ld,
                      dropmask=dropmask)
         if self.training:
+            if dropmask is None:
+                out.bnsrc = dict(bns=[(y, bl)] + ([(y2, bl2)] if y2 is not None else []), relu=relu)
+            if res is not None and res.fuse_ok:
+                res.pending += 1
             self.push("bn_act", lambda: self._bn_act_bwd(y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt),
                       y=y, bm=bm, bl=bl, relu=relu, res=res, y2=y2, bm2=bm2, bl2=bl2, dropmask=dropmask, out=out,
                       cnt=cnt)
@@ -483,17 +515,29 @@ class Engine:
         dout = out.grad
         assert dout is not None and out.ginit
         gy = self.grad_of(y)
-        if res is not None:
-            assert not res.ginit
-            g, ldg = self.grad_of(res), res.ld
-            res.ginit = True
+        if res is not None and res.fuse_ok:
+            res.pending -= 1
+        if out.bn_reduced:
+            # the data gradient that completed out.grad already masked it and accumulated the sums of this layer
+            # (and of the downsample BN): out.grad IS g
+            g, ldg = dout, out.ld
+            if res is not None:
+                assert not res.ginit and res.grad is None and res.ld == out.ld
+                res.grad = dout           # the residual's gradient starts as g; later contributions add in place
+                res.ginit = True
         else:
-            g, ldg = gy, y.ld
-        ops.bn_bwd_reduce(dout, out.ld, out.data if relu else None, out.ld, dropmask, y.H * y.W, y.data,
-                          y.ld, bl.mean, bl.invstd, g, ldg, bl.sums, y.M, y.C, nslot=ops.NSLOT)
+            if res is not None:
+                assert not res.ginit
+                g, ldg = self.grad_of(res), res.ld
+                res.ginit = True
+            else:
+                g, ldg = gy, y.ld
+            ops.bn_bwd_reduce(dout, out.ld, out.data if relu else None, out.ld, dropmask, y.H * y.W, y.data,
+                              y.ld, bl.mean, bl.invstd, g, ldg, bl.sums, y.M, y.C, nslot=ops.NSLOT)
         if y2 is not None:
-            ops.bn_bwd_reduce(g, ldg, None, 0, None, y2.H * y2.W, y2.data, y2.ld, bl2.mean, bl2.invstd,
-                              None, 0, bl2.sums, y2.M, y2.C, nslot=ops.NSLOT)
+            if not out.bn_reduced:
+                ops.bn_bwd_reduce(g, ldg, None, 0, None, y2.H * y2.W, y2.data, y2.ld, bl2.mean, bl2.invstd,
+                                  None, 0, bl2.sums, y2.M, y2.C, nslot=ops.NSLOT)
             ops.bn_param_grads(bl2.sums, bl2.ggrad, bl2.bgrad, bl2.C, nslot=ops.NSLOT)
             self._sync(bl2.sums[:2 * bl2.C])
             gy2 = self.grad_of(y2)
@@ -547,15 +591,23 @@ class Engine:
 
     def bottleneck(self, x, blk, out=None):
         a1 = self.conv_bn(x, blk.conv1, blk.bn1)
+        a1.fuse_ok = self.training            # consumed by conv2 only
         a2 = self.conv_bn(a1, blk.conv2, blk.bn2)
+        a2.fuse_ok = self.training            # consumed by conv3 only
         if not self.training:
             r = x if blk.downsample is None else self.conv_bn(x, blk.downsample[0], blk.downsample[1], relu=False)
             return self.conv_bn(a2, blk.conv3, blk.bn3, relu=True, res=r, out=out)
         y3 = self.conv(a2, blk.conv3, stats=self._st(blk.bn3))
         if blk.downsample is not None:
             yd = self.conv(x, blk.downsample[0], stats=self._st(blk.downsample[1]))
-            return self.bn_act(y3, blk.bn3, y2=yd, bm2=blk.downsample[1], out=out)
-        return self.bn_act(y3, blk.bn3, res=x, out=out)
+            o = self.bn_act(y3, blk.bn3, y2=yd, bm2=blk.downsample[1], out=out)
+        else:
+            o = self.bn_act(y3, blk.bn3, res=x, out=out)
+        # A block output is consumed by the next block's conv1 (+ downsample conv) and as its residual, or by the head
+        # convs: all tracked by Act.pending.  Not when it is a channel slice of the head's concat buffer (the PPM / PSA
+        # pooling and the concat-wide cls conv read it in ways the counter does not see).
+        o.fuse_ok = out is None
+        return o
 
     def trunk(self, x_nchw, cat_C):
         """layer0..layer4; layer4's output lands in channels [0,2048) of the head's concat buffer."""
@@ -761,7 +813,8 @@ class Engine:
         for op in reversed(self.tape):
             self._run(op)
         if self._side_used:
-            torch.cuda.current_stream().wait_stream(self._side)   # join the weight-gradient stream
+            for st in self._sides:
+                torch.cuda.current_stream().wait_stream(st)       # join the weight-gradient stream(s)
             self._side_used = False
 
     def _reset_grad_flags(self):

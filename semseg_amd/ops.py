@@ -92,6 +92,21 @@ def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldad
                               *_scr(scratch), _stream()), "conv_dgrad")
 
 
+def conv_dgrad_bnreduce(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, act, ldact, bns, nslot, add=None, ldadd=0,
+                        scratch=None):
+    """Data gradient fused with the BatchNorm-backward reduction of the layer(s) that produced the conv's input.
+    bns: 1 or 2 tuples (y, ldy, mean, invstd, sums[nslot][2*Ci])."""
+    Ho = conv_out(H, pk.R, stride, pad, dil)
+    Wo = conv_out(W, pk.S, stride, pad, dil)
+    b0 = bns[0]
+    b1 = bns[1] if len(bns) > 1 else (None, 0, None, None, None)
+    _ck(lib.semseg_conv_dgrad_bnreduce(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R,
+                                       pk.S, stride, pad, dil, _p(add), ldadd, pk.tile_dgrad, len(bns), _p(act), ldact,
+                                       _p(b0[0]), b0[1], _p(b0[2]), _p(b0[3]), _p(b0[4]),
+                                       _p(b1[0]), b1[1], _p(b1[2]), _p(b1[3]), _p(b1[4]), nslot, *_scr(scratch),
+                                       _stream()), "conv_dgrad_bnreduce")
+
+
 def wgrad_scratch_floats(Ci, Co, R, S):
     return int(lib.semseg_conv_wgrad_scratch_floats(Ci, Co, R, S))
 

@@ -151,7 +151,15 @@ class InsituChecker:
             if gx0 is not None:
                 gx64 = gx64 + gx0.double()
                 gx32 = gx32 + gx0
-            self._rec("conv", name, "dgrad", _nchw(x.grad, x.C), gx64, gx32)
+            qty = "dgrad"
+            if x.bn_reduced:
+                # this launch also did the BatchNorm-backward reduction of the layer that produced x: what it stored is
+                # g = dx * (x > 0); the sums it accumulated are checked by the BatchNorm entry (dgamma / dbeta / dy)
+                qty = "dgrad+bnr"
+                if x.bnsrc["relu"]:
+                    gx64 = gx64 * (xs > 0)
+                    gx32 = gx32 * (xs > 0)
+            self._rec("conv", name, qty, _nchw(x.grad, x.C), gx64, gx32)
 
     # ------------------------------------------------------------------ BatchNorm (+ReLU, residual, downsample BN)
     @staticmethod

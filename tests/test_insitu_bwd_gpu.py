@@ -69,6 +69,9 @@ def test_insitu_pspnet101_473(report):
     """The metric model at the metric resolution (per-GPU batch 2)."""
     chk = _case(report, "pspnet101 c150 473^2 b2", "psp", 101, 150, 473, 2)
     assert sum(1 for r in chk.rows if r[0] == "conv" and r[2] == "wgrad") == 113   # every MFMA conv of the net
+    # bn1 / bn2 of all 33 bottlenecks and the block outputs (except the one written into the concat buffer) have their
+    # BatchNorm-backward reduction folded into the data gradient that completes their gradient
+    assert sum(1 for r in chk.rows if r[2] == "dgrad+bnr") >= 90
 
 
 @pytest.mark.skipif(os.environ.get("SEMSEG_SKIP_BIG_INSITU") == "1", reason="big in-situ cases disabled")

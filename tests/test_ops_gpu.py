@@ -39,6 +39,56 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, Ci, Co, k, stride, pad, dil, nbn, with_add, split
+    (2, 20, 20, 128, 256, 3, 1, 2, 2, 1, False, False),
+    (2, 20, 20, 128, 256, 3, 1, 2, 2, 1, False, True),      # K-split tiles: fused reduction in the split-K epilogue
+    (3, 15, 15, 256, 64, 1, 1, 0, 1, 2, True, False),       # bn3 + downsample BN sharing g, residual add, M = 675
+    (3, 15, 15, 256, 64, 1, 1, 0, 1, 2, True, True),
+    (7, 60, 60, 128, 64, 1, 1, 0, 1, 1, True, True),        # 197 m-tiles: full tiles AND a split tail in one launch
+    (2, 21, 21, 64, 128, 3, 2, 1, 1, 1, False, False),      # 64-wide tile, strided conv
+])
+def test_conv_dgrad_fused_bn_backward_reduce(case, report):
+    """semseg_conv_dgrad_bnreduce: dx = (dgrad (+ add)) * (act > 0) and fp64 [sum g, sum g * xhat] per channel for one
+    or two BatchNorm layers, against the unfused formula in fp64."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co, k, s, p, d, nbn, with_add, split = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    Ho, Wo = ops.conv_out(H, k, s, p, d), ops.conv_out(W, k, s, p, d)
+    w = torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (Co * k * k) ** 0.5)
+    dy = torch.randn(N, Co, Ho, Wo, generator=g)
+    act = torch.relu(torch.randn(N, Ci, H, W, generator=g))
+    add = torch.randn(N, Ci, H, W, generator=g) if with_add else None
+    ys = [torch.randn(N, Ci, H, W, generator=g) * 2 + 0.5 for _ in range(nbn)]
+    means = [torch.randn(Ci, generator=g) for _ in range(nbn)]
+    invs = [torch.rand(Ci, generator=g) + 0.5 for _ in range(nbn)]
+    dx64 = torch.nn.grad.conv2d_input((N, Ci, H, W), w.double(), dy.double(), stride=s, padding=p, dilation=d)
+    if with_add:
+        dx64 = dx64 + add.double()
+    g64 = dx64 * (act > 0)
+    pk = ops.PackedConv(Co, Ci, k, k, DEV)
+    pk.pack(w.to(DEV))
+    ldy = ops.roundup(Co, 128)
+    dyb = torch.zeros(N, Ho, Wo, ldy, device=DEV)
+    dyb[..., :Co] = nhwc(dy).to(DEV)
+    dxb = nhwc(add).to(DEV).contiguous() if with_add else torch.full((N, H, W, Ci), float("nan"), device=DEV)
+    NS = ops.NSLOT
+    sums = [torch.zeros(NS * 2 * Ci, dtype=torch.float64, device=DEV) for _ in range(nbn)]
+    bns = [(nhwc(ys[b]).to(DEV).contiguous(), Ci, means[b].to(DEV), invs[b].to(DEV), sums[b]) for b in range(nbn)]
+    scratch = torch.empty(16 * 1024 * 1024, device=DEV) if split else None
+    ops.conv_dgrad_bnreduce(dyb, ldy, pk, dxb, Ci, N, H, W, s, p, d, nhwc(act).to(DEV).contiguous(), Ci, bns, NS,
+                            add=dxb if with_add else None, ldadd=Ci, scratch=scratch)
+    e_g = relerr(nchw(dxb), g64)
+    errs = []
+    for b in range(nbn):
+        tot = sums[b].view(NS, 2 * Ci).sum(0).cpu()
+        xh = (ys[b].double() - means[b].double().view(1, -1, 1, 1)) * invs[b].double().view(1, -1, 1, 1)
+        errs.append(relerr(tot[:Ci], g64.sum((0, 2, 3))))
+        errs.append(relerr(tot[Ci:], (g64 * xh).sum((0, 2, 3))))
+    report("fused dgrad + BN-backward reduce %s: g %.2e sums %s" % (case, e_g, " ".join("%.1e" % e for e in errs)))
+    assert e_g < 2e-5 and max(errs) < 2e-5
+
+
 WGRAD_BIG_CASES = [
     # N, H, W, Ci, Co, k, stride, pad, dil  (Ci % 128 == 0, Co >= 128: the 128 x 128 weight-gradient tile)
     (2, 13, 13, 128, 128, 3, 1, 2, 2),     # "same" dilated 3x3: linear gather with border taps out of range
