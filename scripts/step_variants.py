@@ -40,6 +40,8 @@ for r in range(ROUNDS):
             os.environ[kv.split("=")[0]] = kv.split("=")[1]
             if kv.split("=")[0] == "NSIDE":          # number of weight-gradient streams (Engine.n_side)
                 eng.n_side = int(kv.split("=")[1])
+            if kv.split("=")[0] == "FUSE_BNR":       # BatchNorm-backward reduction in the data-gradient epilogue
+                eng.fuse_bnr = kv.split("=")[1] == "1"
         os.environ["SEMSEG_WGRAD_DMA"] = str(dma)
         os.environ["SEMSEG_CONV_DMA"] = str(cdma)
         eng.side_all, eng.hipri_main = bool(side), bool(hipri)

@@ -163,13 +163,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
     const bool relu = !split && p.relu;
     double s1 = 0.0, s2 = 0.0;
     f32x4 bmu[2], bis[2];
-    double bs[2][8];
+    float bs[2][8];
     if (bnr) {
       const int cb = n0 + wn * (BN / 2) + j * 32 + (lane & 7) * 4;      // this lane's 4 columns in the stores below
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) bs[b][k] = 0.0;
+        for (int k = 0; k < 8; ++k) bs[b][k] = 0.f;
         if (b < p.bnr_n && cb < Nout4) {
           bmu[b] = *reinterpret_cast<const f32x4*>(p.bnr_mean[b] + cb);
           bis[b] = *reinterpret_cast<const f32x4*>(p.bnr_invstd[b] + cb);
@@ -218,10 +218,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
               if (b < p.bnr_n) {
                 const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.bnr_y[b] + (size_t)m * p.bnr_ldy[b] + cg);
                 const f32x4 xh = (y4 - bmu[b]) * bis[b];
+                // fp32 over this lane's 8 rows of the block, fp64 from there on (cross-lane fold, atomics): the fp64
+                // converts + FMAs per element were ~6 % of a K = 256 tile
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                  bs[b][k] += (double)v[k];
-                  bs[b][4 + k] += (double)v[k] * (double)xh[k];
+                  bs[b][k] += v[k];
+                  bs[b][4 + k] = fmaf(v[k], xh[k], bs[b][4 + k]);
                 }
               }
           }
@@ -235,7 +237,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
           if (b < p.bnr_n) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              double t = bs[b][k];
+              double t = (double)bs[b][k];
               t += shfl_xor_f64(t, 8);
               t += shfl_xor_f64(t, 16);
               t += shfl_xor_f64(t, 32);
