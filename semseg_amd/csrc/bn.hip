@@ -168,18 +168,30 @@ struct ApplyArgs {
 __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
   const int CV = p.C >> 2;
   const size_t total = (size_t)p.M * CV;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * 256) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t idx0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool fixed = stride % CV == 0;       // this thread keeps its 4 channels: per-channel vectors loaded once
+  const int c0 = (int)(idx0 % CV) * 4;
+  f32x4 sc0, sh0, sc20, sh20;
+  if (fixed && idx0 < total) {
+    sc0 = *reinterpret_cast<const f32x4*>(p.scale + c0);
+    sh0 = *reinterpret_cast<const f32x4*>(p.shift + c0);
+    if (p.y2) {
+      sc20 = *reinterpret_cast<const f32x4*>(p.scale2 + c0);
+      sh20 = *reinterpret_cast<const f32x4*>(p.shift2 + c0);
+    }
+  }
+  for (size_t idx = idx0; idx < total; idx += stride) {
     const int m = (int)(idx / CV);
-    const int c = (int)(idx - (size_t)m * CV) * 4;
+    const int c = fixed ? c0 : (int)(idx - (size_t)m * CV) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(p.y + (size_t)m * p.ldy + c);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c);
+    const f32x4 sc = fixed ? sc0 : *reinterpret_cast<const f32x4*>(p.scale + c);
+    const f32x4 sh = fixed ? sh0 : *reinterpret_cast<const f32x4*>(p.shift + c);
     v = v * sc + sh;
     if (p.y2) {
       const f32x4 v2 = *reinterpret_cast<const f32x4*>(p.y2 + (size_t)m * p.ldy2 + c);
-      const f32x4 sc2 = *reinterpret_cast<const f32x4*>(p.scale2 + c);
-      const f32x4 sh2 = *reinterpret_cast<const f32x4*>(p.shift2 + c);
+      const f32x4 sc2 = fixed ? sc20 : *reinterpret_cast<const f32x4*>(p.scale2 + c);
+      const f32x4 sh2 = fixed ? sh20 : *reinterpret_cast<const f32x4*>(p.shift2 + c);
       v += v2 * sc2 + sh2;
     }
     if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + c);
@@ -269,8 +281,46 @@ struct BwdApplyArgs {
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p) {
   const int CV = p.C >> 2;
   const size_t total = (size_t)p.M * CV;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * 256) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t idx0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (stride % CV == 0) {
+    // Every power-of-two channel count of the network: a thread keeps the same 4 channels over its whole row walk, so
+    // the 8 fp64 sums and the 3 parameter vectors are read ONCE per thread instead of once per element.
+    if (idx0 >= total) return;
+    const int c = (int)(idx0 % CV) * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(p.invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+    f32x4 A, mg, AX;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mg[k] = (float)(p.sums[c + k] * p.inv_count);
+      A[k] = ga[k] * is[k];
+      AX[k] = A[k] * (float)(p.sums[p.C + c + k] * p.inv_count);
+    }
+    const int mstep = (int)(stride / CV);
+    constexpr int U = 4;   // rows in flight per thread
+    for (int m = (int)(idx0 / CV); m < p.M; m += U * mstep) {
+      f32x4 g[U], yy[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int mm = m + u * mstep < p.M ? m + u * mstep : m;
+        g[u] = *reinterpret_cast<const f32x4*>(p.g + (size_t)mm * p.ldg + c);
+        yy[u] = *reinterpret_cast<const f32x4*>(p.y + (size_t)mm * p.ldy + c);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int mm = m + u * mstep;
+        if (mm < p.M) {
+          const f32x4 xh = (yy[u] - mu) * is;
+          const f32x4 r = A * (g[u] - mg) - AX * xh;      // = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))
+          *reinterpret_cast<f32x4*>(p.dy + (size_t)mm * p.lddy + c) = r;
+        }
+      }
+    }
+    return;
+  }
+  for (size_t idx = idx0; idx < total; idx += stride) {
     const int m = (int)(idx / CV);
     const int c = (int)(idx - (size_t)m * CV) * 4;
     const f32x4 g = *reinterpret_cast<const f32x4*>(p.g + (size_t)m * p.ldg + c);
