@@ -1654,12 +1654,16 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     full_tiles = 0;
     tail_mt = tiles_m;
   } else if (can_split) {
+    // SEMSEG_TAIL_SPLIT (read per call, A/B): 0 = no stream-K tail (the last partial round runs whole tiles), n > 1 =
+    // cap of the tail's K split (default 16)
+    const char* ts = getenv("SEMSEG_TAIL_SPLIT");
+    const int tcap = ts ? atoi(ts) : 16;
     const int rem = tiles % P;
-    if (rem != 0 && rem <= 208) {
+    if (tcap > 1 && rem != 0 && rem <= 208) {
       tail_mt = (rem + p.tiles_n - 1) / p.tiles_n;
       if (tail_mt > tiles_m) tail_mt = tiles_m;
       full_tiles = tiles - tail_mt * p.tiles_n;
-      ksplit = 16;
+      ksplit = tcap;
       while (ksplit > 1 && ksplit > KT / 4) ksplit >>= 1;
       if (ksplit == 1) { full_tiles = tiles; tail_mt = 0; }
     }
