@@ -194,6 +194,50 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
           }
         }
       // same-wave LDS traffic is ordered: no barrier needed between the writes above and these reads
+      if (bnr) {
+        // Fused BatchNorm-backward reduction.  One row per iteration, its five operand loads issued together and the
+        // loop NOT unrolled: guarded per-operand loads cost up to three dependent HBM round trips per row (+22 % on the
+        // K = 256 data gradients), while unrolling lets the compiler hoist the loads of several rows and grow the
+        // kernel from 159 to 223 VGPRs (residency 3 -> 2, and no room beside the weight-gradient workgroups).
+        // Out-of-range rows / columns load from a clamped address and are dropped at the store; absent operands (no
+        // residual add, no second BatchNorm, no ReLU mask) alias a present one and are neutralised arithmetically.
+        const bool has_add = p.add != nullptr, has_mask = p.bnr_mask != nullptr, two = p.bnr_n > 1;
+        const float* addp = has_add ? p.add : p.bnr_y[0];
+        const int ldap = has_add ? p.ldadd : p.bnr_ldy[0];
+        const float addw = has_add ? 1.f : 0.f;
+        const float* maskp = has_mask ? p.bnr_mask : p.bnr_y[0];
+        const int ldmp = has_mask ? p.bnr_ldm : p.bnr_ldy[0];
+        const float* y1p = two ? p.bnr_y[1] : p.bnr_y[0];
+        const int ldy1 = two ? p.bnr_ldy[1] : p.bnr_ldy[0];
+        const int c4 = (lane & 7) * 4;
+        const int cg = n0 + wn * (BN / 2) + j * 32 + c4;
+        const int cc = cg < colmax ? cg : 0;
+#pragma nounroll
+        for (int h = 0; h < 8; ++h) {
+          const int lr = (lane >> 3) + 8 * h;
+          const int m = m0 + wm * 64 + lr;
+          const bool ok = m < p.M && cg < colmax;
+          const size_t mm = (size_t)(m < p.M ? m : p.M - 1);
+          const f32x4 vv = *reinterpret_cast<const f32x4*>(&wl[lr * LDK + c4]);
+          const f32x4 aa = *reinterpret_cast<const f32x4*>(maskp + mm * ldmp + cc);
+          const f32x4 dd = *reinterpret_cast<const f32x4*>(addp + mm * ldap + cc);
+          const f32x4 y0 = *reinterpret_cast<const f32x4*>(p.bnr_y[0] + mm * p.bnr_ldy[0] + cc);
+          const f32x4 y1 = *reinterpret_cast<const f32x4*>(y1p + mm * ldy1 + cc);
+          f32x4 v = vv + addw * dd;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = ((!has_mask || aa[k] > 0.f) && ok) ? v[k] : 0.f;
+          const f32x4 xh0 = (y0 - bmu[0]) * bis[0];
+          const f32x4 xh1 = (y1 - bmu[1]) * bis[1];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            bs[0][k] += v[k];
+            bs[0][4 + k] = fmaf(v[k], xh0[k], bs[0][4 + k]);
+            bs[1][k] += v[k];
+            bs[1][4 + k] = fmaf(v[k], xh1[k], bs[1][4 + k]);
+          }
+          if (ok) *reinterpret_cast<f32x4*>(dst + (size_t)(m - mrow0) * ldd + cg) = v;
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int idx = lane + 64 * t;
@@ -207,28 +251,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
           }
-          if (bnr) {
-            if (p.bnr_mask) {
-              const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.bnr_mask + (size_t)m * p.bnr_ldm + cg);
-#pragma unroll
-              for (int k = 0; k < 4; ++k) v[k] = a4[k] > 0.f ? v[k] : 0.f;
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-              if (b < p.bnr_n) {
-                const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.bnr_y[b] + (size_t)m * p.bnr_ldy[b] + cg);
-                const f32x4 xh = (y4 - bmu[b]) * bis[b];
-                // fp32 over this lane's 8 rows of the block, fp64 from there on (cross-lane fold, atomics): the fp64
-                // converts + FMAs per element were ~6 % of a K = 256 tile
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  bs[b][k] += v[k];
-                  bs[b][4 + k] = fmaf(v[k], xh[k], bs[b][4 + k]);
-                }
-              }
-          }
           *reinterpret_cast<f32x4*>(dst + (size_t)(m - mrow0) * ldd + cg) = v;
         }
+      }
       }
       if (bnr) {
         // lanes with equal (lane & 7) hold the same 4 columns for different rows: fold them, lanes 0-7 keep the totals
