@@ -217,6 +217,12 @@ int semseg_intersection_and_union(const long long* pred, const long long* target
                                   float* area_intersection, float* area_union, float* area_target,
                                   hipStream_t stream);
 
+/* Dropout2d(p) keep/scale mask, one value per (n, c) plane (model/pspnet.py:68,76): 1/(1-p) with probability 1-p,
+ * else 0; counter-based generator keyed by (seed, offset, plane).  semseg_memset_zero: hipMemsetAsync on the stream. */
+int semseg_dropout2d_mask(float* mask, int n, float p, unsigned long long seed, unsigned long long offset,
+                          hipStream_t stream);
+int semseg_memset_zero(void* ptr, size_t bytes, hipStream_t stream);
+
 /* ---- torch.optim.SGD step (tool/train.py:140,276) over a flat range. */
 int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, float lr, const float* lr_dev,
                     float momentum, float weight_decay, float grad_scale, int first_step,

@@ -28,7 +28,34 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const f
     }
   }
 }
+// Dropout2d keep/scale mask (model/pspnet.py:68,76: nn.Dropout2d(p) zeroes whole (n, c) planes and scales the kept
+// ones by 1/(1-p)): one value per plane from a counter-based generator (splitmix64 of seed, call offset and plane
+// index) — same distribution as torch's, not the same bit stream (semantics, not bit patterns).
+__global__ void dropout2d_mask_kernel(float* __restrict__ mask, int n, float keep, float scale,
+                                      unsigned long long seed, unsigned long long offset) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (offset * 0x100000000ull + (unsigned long long)i + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0, 1)
+  mask[i] = u < keep ? scale : 0.f;
+}
 }  // namespace
+
+extern "C" int semseg_dropout2d_mask(float* mask, int n, float p, unsigned long long seed, unsigned long long offset,
+                                     hipStream_t stream) {
+  if (!mask || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return SEMSEG_EINVAL;
+  dropout2d_mask_kernel<<<(n + 255) / 256, 256, 0, stream>>>(mask, n, 1.f - p, 1.f / (1.f - p), seed, offset);
+  return semseg_launch_status();
+}
+
+extern "C" int semseg_memset_zero(void* ptr, size_t bytes, hipStream_t stream) {
+  if (!ptr) return SEMSEG_EINVAL;
+  if (bytes == 0) return SEMSEG_OK;
+  return hipMemsetAsync(ptr, 0, bytes, stream) == hipSuccess ? SEMSEG_OK : SEMSEG_ELAUNCH;
+}
 
 extern "C" int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, float lr,
                                const float* lr_dev, float momentum, float weight_decay,

@@ -5,7 +5,7 @@ reference's state-dict names; this engine walks that tree once per (batch, H, W,
 activation / gradient buffer (NHWC fp32, explicit channel stride), and issues the C-ABI kernels
 (include/semseg_hip.h) on the current HIP stream.  Forward appends backward closures to a tape; the
 backward pass replays it in reverse.  No torch compute op is on the path (torch = device memory,
-streams, RNG for the Dropout2d mask, torch.distributed for the SyncBN / gradient all-reduce).
+streams, the seed of the Dropout2d mask generator, torch.distributed for the SyncBN / gradient all-reduce).
 
 Reference call structure mirrored here: model/pspnet.py:80-105 (PSPNet.forward),
 model/resnet.py:74-94 (Bottleneck.forward), model/pspnet.py:21-26 (PPM.forward),
@@ -180,6 +180,7 @@ class Engine:
         self._side_used = False
         self._mod_ids = tuple(id(m) for m in model.modules())
         self._labels_checked = False
+        self._drop_calls = 0
         self.tape_hook = None  # callable(TapeOp) that must call op.fn(); set by tests only
 
     def push(self, kind, fn, **ctx):
@@ -358,7 +359,7 @@ class Engine:
             # bias gradient = per-channel sum of dy (fp64 reduction, then the [C] cast kernel)
             C4 = ops.roundup(cl.Co, 4)
             st = self._bias_stats(C4)
-            st.zero_()
+            ops.zero_(st)
             ops.channel_stats(dy, y.ld, st, y.M, C4)
             ops.bn_param_grads(st, self._dummy(C4), cl.bgrad, cl.Co)
             ready.append(m.bias)
@@ -687,7 +688,9 @@ class Engine:
         dm = None
         if self.training and drop.training and drop.p > 0:
             dm = self.buf((x.N, conv_a.weight.shape[0]), tag="dropmask")
-            dm.bernoulli_(1.0 - drop.p).mul_(1.0 / (1.0 - drop.p))
+            # seeded from torch's generator state (torch.manual_seed reproduces a run), advanced per call
+            self._drop_calls += 1
+            ops.dropout2d_mask(dm, drop.p, torch.initial_seed(), self._drop_calls)
         a = self.conv_bn(x, conv_a, bn_a, dropmask=dm)
         ncls = conv_b.weight.shape[0]
         out = self.act(x.N, x.H, x.W, ncls, ld=ops.roundup(ncls, 128), tag="scores" + tag)
@@ -727,7 +730,7 @@ class Engine:
             self.pack_weights()
             self.weights_version = sig
         if self.training:
-            self._f64_arena.zero_()
+            ops.zero_(self._f64_arena)
             self.model.__dict__["_hip_bn_epoch"] = self.model.__dict__.get("_hip_bn_epoch", 0) + 1
         else:
             # eval-mode scale/shift are cached until the weights, the running statistics (torch-side
@@ -825,4 +828,4 @@ class Engine:
 
     def _f64_zero_sums(self):
         # stats and sums share the arena; stats are dead after forward
-        self._f64_arena.zero_()
+        ops.zero_(self._f64_arena)

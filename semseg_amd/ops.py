@@ -244,6 +244,17 @@ def ce_head_bwd(scores, ld, label, lse, acc2, grad_loss, grad_mul, dscores, lddz
                                ignore_index, *_scr(scratch), _stream()), "ce_head_bwd")
 
 
+def dropout2d_mask(mask, p, seed, offset):
+    _ck(lib.semseg_dropout2d_mask(_p(mask), mask.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset),
+                                  _stream()), "dropout2d_mask")
+
+
+def zero_(t):
+    """hipMemsetAsync on the current stream (no torch fill kernel on the path)."""
+    assert t.is_contiguous()
+    _ck(lib.semseg_memset_zero(_p(t), t.numel() * t.element_size(), _stream()), "memset_zero")
+
+
 def label_check(label, C, ignore_index):
     """Number of targets that are neither ignore_index nor a class id (synchronises)."""
     assert label.dtype == torch.int64 and label.is_cuda and label.is_contiguous()

@@ -80,3 +80,24 @@ def test_insitu_psanet101_465(report):
     cfg = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=59, mask_w=59, normalization_factor=1.0,
                psa_softmax=True)
     _case(report, "psanet101 c150 465^2 b2 mask59", "psa", 101, 150, 465, 2, psa_cfg=cfg)
+
+
+def test_insitu_pspnet50_with_dropout(report):
+    """Dropout2d(0.1) active in both heads (the bench configuration): the in-situ check of the head BatchNorm layers
+    uses the mask the HIP path drew (semseg_dropout2d_mask), so the mask-aware backward (bn_bwd_reduce with the
+    per-plane keep/scale factor) is checked against fp64 like every other op."""
+    from oracle import segnet
+    from model.pspnet import PSPNet
+    from insitu import run_insitu
+    torch.manual_seed(11)
+    m = PSPNet(layers=50, classes=21, zoom_factor=8, dropout=0.1, pretrained=False)
+    m.load_state_dict(segnet.recipe_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234))
+    x, y = inputs(2, 73, 21)
+    m = m.cuda().train()
+    chk, ml, al = run_insitu(m, x.cuda(), y.cuda(), report)
+    report("in-situ backward parity with Dropout2d(0.1), pspnet50 73^2 b2:\n%s" % chk.summary())
+    assert ml == ml and al == al     # finite
+    bad = chk.failures()
+    assert not bad, bad[:8]
+    heads = [r for r in chk.rows if r[0] == "bn_act" and r[1] in ("cls.1", "aux.1")]
+    assert len(heads) == 6

@@ -650,6 +650,26 @@ def test_lib_psa_functional_dropin(report):
     report("lib.psa.functional.psa_mask == reference golden vectors (%d cases), checks ok" % len(keys))
 
 
+def test_dropout2d_mask_statistics(report):
+    """semseg_dropout2d_mask: one Bernoulli(1-p) per (n, c) plane scaled by 1/(1-p) (nn.Dropout2d, model/pspnet.py:68);
+    deterministic in (seed, offset), different across offsets."""
+    from semseg_amd import ops
+    n, p = 1 << 16, 0.1
+    a = torch.empty(n, device=DEV)
+    b = torch.empty(n, device=DEV)
+    c = torch.empty(n, device=DEV)
+    ops.dropout2d_mask(a, p, 1234, 1)
+    ops.dropout2d_mask(b, p, 1234, 1)
+    ops.dropout2d_mask(c, p, 1234, 2)
+    vals = torch.unique(a).cpu().tolist()
+    keep = float((a > 0).float().mean())
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / 0.9) < 1e-6
+    assert abs(keep - 0.9) < 0.005 and abs(float(a.mean()) - 1.0) < 0.01
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(((a > 0) & (c > 0)).float().mean()) - 0.81) < 0.01          # independent across offsets
+    report("dropout2d mask: keep fraction %.4f (p = 0.1), mean %.4f, reproducible per (seed, offset)" % (keep, float(a.mean())))
+
+
 def test_intersection_and_union(report):
     """util/util.py:40-52 (numpy form) is the oracle for the device kernel (util/util.py:55-67 form)."""
     import numpy as np
