@@ -321,6 +321,27 @@ def test_out_of_range_labels_raise_like_torch(report):
     report("out-of-range label raises IndexError; ignore_index passes")
 
 
+def test_trainer_detects_broken_parameter_aliasing(report):
+    """Trainer rebinds every parameter to a view of one flat buffer; anything that re-materialises the
+    parameters afterwards (model.to(), load_state_dict(assign=True), ...) would make SGD update a buffer nobody reads.
+    step() checks the aliasing and raises instead of training on stale weights."""
+    from model.pspnet import PSPNet
+    from semseg_amd.trainer import Trainer
+    m = PSPNet(layers=50, classes=5, zoom_factor=8, dropout=0.0, pretrained=False).cuda().train()
+    tr = Trainer(m, base_lr=0.01)
+    x = torch.randn(2, 3, 41, 41).cuda()
+    y = torch.randint(0, 5, (2, 41, 41)).cuda()
+    tr.step(x, y)
+    w_before = m.layer0[0].weight.detach().clone()
+    tr.step(x, y)
+    assert not torch.equal(w_before, m.layer0[0].weight.detach())          # SGD really moves the module's weights
+    p = next(m.parameters())
+    p.data = p.data.clone()                                                 # what model.to(...) / assign=True do
+    with pytest.raises(RuntimeError, match="no longer alias"):
+        tr.step(x, y)
+    report("Trainer: parameters alias the flat buffer (weights move), broken aliasing raises")
+
+
 def test_argument_checks():
     """The reference's assertions (model/pspnet.py:32-35,82)."""
     from model.pspnet import PSPNet
