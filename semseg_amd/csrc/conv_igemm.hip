@@ -1516,24 +1516,29 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
     }
 }
 
-// dW partial slabs [ksplit][Co_pad][RS][Ci] -> OIHW gradient [Co][Ci][R][S] (sum over ksplit).
-__global__ void wgrad_reduce_unpack_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                           int ksplit, int Co, int Co_pad, int Ci, int RS,
-                                           int accumulate, long long part_bs, long long dw_bs) {
-  const size_t total = (size_t)Co * Ci * RS;
+// dW partial slabs [ksplit][Co_pad][RS][Ci] -> OIHW gradient [Co][Ci][R][S] (sum over ksplit, in slab order:
+// deterministic).  Threads walk the SLAB layout, four input channels per thread: the ksplit reads (the bulk of the
+// traffic) are 16-byte coalesced, the four OIHW stores are RS floats apart (round 1 walked the OIHW order: for 3x3
+// kernels every slab read was a 4-byte access at a Ci-float stride, and every index was a 64-bit div/mod).
+__global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                  int ksplit, int Co, int Co_pad, int Ci, int RS,
+                                                                  int accumulate, long long part_bs, long long dw_bs) {
   const size_t slab = (size_t)Co_pad * RS * Ci;
   part += (size_t)blockIdx.y * part_bs;   // batched K-major GEMM: blockIdx.y = batch item
   dw += (size_t)blockIdx.y * dw_bs;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    const int tap = (int)(idx % RS);
-    const size_t t = idx / RS;
-    const int ci = (int)(t % Ci);
-    const int co = (int)(t / Ci);
-    const size_t src = ((size_t)co * RS + tap) * Ci + ci;
-    float v = 0.f;
-    for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * slab + src];
-    dw[idx] = accumulate ? dw[idx] + v : v;
+  const int CV = Ci >> 2;                 // Ci % 4 == 0 (the weight-gradient kernels need Ci % 64 == 0)
+  const int total = Co * RS * CV;         // float4 groups of the valid rows, slab order (co, tap, ci)
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
+    const int c4 = g % CV;
+    const int t = g / CV;
+    const int tap = t % RS;
+    const int co = t / RS;
+    const size_t src = (size_t)g * 4;     // = ((co * RS + tap) * Ci + c4 * 4)
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + src);
+    for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(part + (size_t)k * slab + src);
+    float* o = dw + ((size_t)co * Ci + c4 * 4) * RS + tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[(size_t)j * RS] = accumulate ? o[(size_t)j * RS] + v[j] : v[j];
   }
 }
 
@@ -1990,7 +1995,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   else if (big) LAUNCH_WGRAD(128, 128); else LAUNCH_WGRAD(64, 64);
 #undef LAUNCH_WGRAD_DMA
 #undef LAUNCH_WGRAD
-  const size_t total = (size_t)Co * Ci * RS;
+  const size_t total = (size_t)Co * Ci * RS / 4;   // one thread per 4 input channels
   wgrad_reduce_unpack_kernel<<<dim3(grid_for(total, 256), batch), 256, 0, stream>>>(
       scratch, dw_oihw, ksplit, Co, a.Co_pad, Ci, RS, accumulate, a.dw_bs, out_bs);
   return semseg_launch_status();
