@@ -26,7 +26,7 @@ def _round(x):
 
 class MultiScaleTester:
     def __init__(self, model, classes, base_size, crop_h, crop_w, scales=(1.0,), mean=None, std=None,
-                 stride_rate=2.0 / 3.0, max_batch_crops=16, shard=True, group=None, all_ranks=False):
+                 stride_rate=2.0 / 3.0, max_batch_crops=16, shard=False, group=None, all_ranks=False):
         value_scale = 255
         self.model = model.eval()
         self.classes = classes
@@ -146,9 +146,10 @@ class MultiScaleTester:
     def predict(self, image_hwc, return_prob=False):
         """image_hwc: float32 [H,W,3] RGB in 0..255 (what SemData + ToTensor hand to test.py:188-190).
 
-        Under torch.distributed (shard=True) every rank passes the SAME image; the crops are sharded over the
-        ranks and the [C,h,w] probability sums are combined by ONE reduce to rank 0 (`all_ranks=True`: all-reduce).
-        Ranks that do not receive the result return None."""
+        With `shard=True` (opt-in: it is a collective) and torch.distributed initialised, every rank must pass the
+        SAME image; the crops are sharded over the ranks and the [C,h,w] probability sums are combined by ONE reduce
+        to rank 0 (`all_ranks=True`: all-reduce).  Ranks that do not receive the result return None.  The default
+        (`shard=False`) is the reference's mode: each process handles whole images on its own (tool/test.py:88-93)."""
         dist, rank, world = self._dist()
         img = torch.as_tensor(image_hwc, dtype=torch.float32, device=self.device).contiguous()
         h, w, _ = img.shape

@@ -27,7 +27,7 @@ def main(out):
     sd["cls.4.bias"] *= 1e-3
     m.load_state_dict(sd)
     img = (np.random.default_rng(1).random((97, 130, 3)) * 255).astype(np.float32)
-    t = MultiScaleTester(m.cuda(), classes, base, crop, crop, (0.5, 1.0, 1.75))
+    t = MultiScaleTester(m.cuda(), classes, base, crop, crop, (0.5, 1.0, 1.75), shard=True)
     pred, prob = t.predict(img, return_prob=True)
     torch.cuda.synchronize()
     units = t.shard_units(t.plan(97, 130), rank, world)
