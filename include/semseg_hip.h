@@ -210,6 +210,53 @@ int semseg_resize_accumulate_chw(const float* canvas_chw, const float* count, in
                                  float weight, hipStream_t stream);
 int semseg_argmax_chw(const float* prob_chw, long long* out, int C, int H, int W, hipStream_t stream);
 
+/* ---- training input pipeline on the device: the reference's transform chain
+ * util/transform.py:76-241 (composed at tool/train.py:194-201,209-212, applied per sample at util/dataset.py:67-69),
+ * which runs cv2 on CPU workers.  The host plans every sample first (parameters depend only on sizes) and hands the
+ * device one op descriptor per sample per round; a round is ONE launch for the whole batch.  Each op reads the
+ * materialised region (ROI) of a virtual src_H x src_W image and writes the region dst_{y0,x0,h,w} of its virtual
+ * dst_H x dst_W output: only pixels that can reach the final crop are ever computed.  Pointers are device addresses.
+ *   RESIZE  cv2.resize INTER_LINEAR (float image) + INTER_NEAREST (uint8 label), transform.py:71-72,101-102;
+ *           p[0], p[1] = 1/inv_scale_x, 1/inv_scale_y as OpenCV forms them
+ *   ROTATE  cv2.warpAffine INTER_LINEAR / INTER_NEAREST, BORDER_CONSTANT, transform.py:192-194;
+ *           p[0..5] = the inverted 2x3 matrix (source = M * destination)
+ *   BLUR    cv2.GaussianBlur((k,k), 0), k in {1,3,5,7}, BORDER_REFLECT_101, transform.py:226 (label passes through)
+ *   GATHER  a chain of index maps applied output -> source: cv2.flip (transform.py:204-205,215-216),
+ *           copyMakeBorder + slice (Crop, transform.py:144-164), channel swap (transform.py:233,240); with out_chw
+ *           also ToTensor (transform.py:24-41) and Normalize (transform.py:54-61): float [3,h,w] + int64 [h,w].
+ * Image source is uint8 (src_u8 = 1, the decoded image) or float32 HWC; intermediate outputs are float32 HWC +
+ * uint8 label, dense over the destination ROI. */
+enum { SEMSEG_AUG_NONE = 0, SEMSEG_AUG_RESIZE = 1, SEMSEG_AUG_ROTATE = 2, SEMSEG_AUG_BLUR = 3, SEMSEG_AUG_GATHER = 4 };
+#define SEMSEG_AUG_MAX_MAPS 6
+typedef struct semseg_aug_map {
+  int in_h, in_w;        /* size of the map's input image; outside it the output takes pad / pad_lab */
+  int sy, oy, sx, ox;    /* input (y, x) = (sy*y + oy, sx*x + ox), sy, sx in {+1, -1} */
+  int swap_rb;           /* output channel c reads input channel 2-c */
+  int pad_lab;
+  float pad[3];
+  int reserved;
+} semseg_aug_map;
+typedef struct semseg_aug_op {
+  int kind, src_u8;
+  unsigned long long src_img, src_lab, dst_img, dst_lab;
+  int src_H, src_W, src_y0, src_x0, src_h, src_w;
+  int dst_H, dst_W, dst_y0, dst_x0, dst_h, dst_w;
+  double p[6];
+  float pad[3];
+  int pad_lab;
+  int ksize;
+  int n_maps;
+  int out_chw;           /* GATHER: 1 = write float CHW planes [3, dst_h, dst_w] + int64 label */
+  int normalize;         /* with out_chw: 0 none, 1 subtract mean, 2 subtract mean and divide by std */
+  float mean[3], std[3];
+  int reserved[2];
+  semseg_aug_map maps[SEMSEG_AUG_MAX_MAPS];
+} semseg_aug_op;
+/* ops_dev: n_samples descriptors of this round (kind NONE = the sample has no op in this round); max_pixels = the
+ * largest dst_h*dst_w among them (sizes the grid). */
+int semseg_augment_round(const semseg_aug_op* ops_dev, int n_samples, int max_pixels, hipStream_t stream);
+int semseg_aug_op_size(void);   /* sizeof(semseg_aug_op), for binding self-checks */
+
 /* ---- intersectionAndUnionGPU (util/util.py:55-67; tool/train.py:286,375): one pass over int64
  * prediction/target, hist3K = 3*K uint64 scratch, outputs fp32 [K] each like torch.histc returns. */
 int semseg_intersection_and_union(const long long* pred, const long long* target, size_t n, int K,

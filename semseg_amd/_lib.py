@@ -25,7 +25,7 @@ def parse_header(path=HEADER):
         alist = []
         for a in args.split(","):
             a = " ".join(a.split())
-            if not a:
+            if not a or a == "void":
                 continue
             if "*" in a:
                 ct = ctypes.c_void_p

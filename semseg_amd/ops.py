@@ -366,3 +366,13 @@ def resize_accumulate_chw(canvas, count, Hc, Wc, y0, x0, Hs, Ws, dst, Hd, Wd, C,
 
 def argmax_chw(prob, out, C, H, W):
     _ck(lib.semseg_argmax_chw(_p(prob), _p(out), C, H, W, _stream()), "argmax_chw")
+
+
+# ---------------------------------------------------------------------------------------------
+# training input pipeline (util/transform.py) on the device; planned by semseg_amd/transform.py
+# ---------------------------------------------------------------------------------------------
+def augment_round(ops_dev, n_samples, max_pixels):
+    """ops_dev: uint8 CUDA tensor holding n_samples semseg_aug_op descriptors."""
+    assert ops_dev.is_cuda and ops_dev.dtype == torch.uint8
+    assert ops_dev.numel() >= n_samples * lib.semseg_aug_op_size()
+    _ck(lib.semseg_augment_round(_p(ops_dev), n_samples, max_pixels, _stream()), "augment_round")
