@@ -36,6 +36,9 @@ res = {c: [] for c in CONFIGS}
 for r in range(ROUNDS):
     for c in CONFIGS:
         dma, side, hipri, cdma, extra = c
+        for c2 in CONFIGS:                              # a key one config sets must not leak into the next
+            for kv in [e for e in c2[4].split("+") if e]:
+                os.environ.pop(kv.split("=")[0], None)
         for kv in [e for e in extra.split("+") if e]:
             os.environ[kv.split("=")[0]] = kv.split("=")[1]
             if kv.split("=")[0] == "NSIDE":          # number of weight-gradient streams (Engine.n_side)

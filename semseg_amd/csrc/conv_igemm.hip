@@ -126,7 +126,29 @@ struct ConvArgs {
   const float* bnr_mean[2];
   const float* bnr_invstd[2];
   double* bnr_sums[2];            // [stats_nslot][2 * Nout]
+  int gm;                         // tile rows per group of the workgroup order (decode_tile); <= 1: row-major
 };
+
+// Linear tile index -> (tile_m, tile_n).  Whole (unsplit) tiles are walked in groups of `gm` tile rows, row index
+// fastest inside a group: the ~64 workgroups resident on an XCD then cover gm row blocks x 64/gm weight panels and
+// stream K together, instead of 64/tiles_n rows x ALL weight panels (cls.0's data gradient: 32 panels = 75 MB of
+// weights re-streamed from HBM for every pair of tile rows).  The stream-K tail keeps the row-major order its slab
+// addressing assumes (tail tiles are the last tail rows).
+__device__ __forceinline__ void decode_tile(const ConvArgs& p, int tile, int& tile_m, int& tile_n) {
+  if (p.gm > 1 && tile < p.full_tiles) {
+    const int rows_full = p.full_tiles / p.tiles_n;
+    const int per_group = p.gm * p.tiles_n;
+    const int g = tile / per_group;
+    const int first = g * p.gm;
+    const int gs = min(p.gm, rows_full - first);
+    const int t = tile - g * per_group;
+    tile_n = t / gs;
+    tile_m = first + (t - tile_n * gs);
+  } else {
+    tile_m = fdiv(tile, p.div_tn);
+    tile_n = tile - tile_m * p.tiles_n;
+  }
+}
 
 // ---- epilogue shared by the register-staged and the direct-to-LDS kernels ----
 template <int BM, int BN>
@@ -399,8 +421,8 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
     tile = p.full_tiles + uq;
     split = p.ksplit > 1;
   }
-  const int tile_m = fdiv(tile, p.div_tn);
-  const int tile_n = tile - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  decode_tile(p, tile, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int RS = p.R * p.S;
@@ -748,8 +770,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const ConvArgs p
     tile = p.full_tiles + uq;
     split = p.ksplit > 1;
   }
-  const int tile_m = fdiv(tile, p.div_tn);
-  const int tile_n = tile - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  decode_tile(p, tile, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int nchunk = p.Kc / BK;
@@ -1122,6 +1144,7 @@ struct WgradArgs {
   // batched K-major GEMM (blockIdx.y = batch item): operand / slab strides in floats
   int batch;
   long long x_bs, dy_bs, dw_bs;
+  int order;  // direct-to-LDS kernel: workgroup order inside a K slice (see conv_wgrad_dma_kernel)
 };
 
 // MODE 0: generic gather (any stride / padding).  MODE 1: 1x1, stride 1, pad 0 — the gathered row IS row m,
@@ -1343,10 +1366,29 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
 #else
   int b = blockIdx.x;
 #endif
-  const int tci = b % p.tiles_ci; b /= p.tiles_ci;
-  const int tco = b % p.tiles_co; b /= p.tiles_co;
-  const int tap = b % RS;
-  const int ks = b / RS;
+  // Order inside a K slice decides which operand block the ~64 workgroups resident on an XCD share through its L2
+  // (a workgroup streams one x block [pixels, 128 ci] and one dy block [pixels, 128 co]):
+  //   0: ci tile fastest, then co tile, then tap   (64 neighbours: 1 tap, 2 co tiles, 32 ci tiles -> 34 blocks)
+  //   1: tap fastest, then co tile, ci tile slowest (the 9 taps of a tile pair are neighbours and share BOTH blocks;
+  //      64 neighbours of a 4 x 32 x 9 grid touch 2 x blocks + 4 dy blocks)
+  //   2: tap fastest, then ci tile, co tile slowest
+  const int per_ks = p.tiles_ci * p.tiles_co * RS;
+  const int ks = b / per_ks;
+  b -= ks * per_ks;
+  int tci, tco, tap;
+  if (p.order == 1) {
+    tap = b % RS; b /= RS;
+    tco = b % p.tiles_co;
+    tci = b / p.tiles_co;
+  } else if (p.order == 2) {
+    tap = b % RS; b /= RS;
+    tci = b % p.tiles_ci;
+    tco = b / p.tiles_ci;
+  } else {
+    tci = b % p.tiles_ci; b /= p.tiles_ci;
+    tco = b % p.tiles_co;
+    tap = b / p.tiles_co;
+  }
   const int r = tap / p.S, s = tap - r * p.S;
   const int co0 = tco * TM, ci0 = tci * TN;
   const int kbeg = ks * p.kper;
@@ -1717,6 +1759,10 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   p.div_w = make_fastdiv(a.Wout);
   p.div_tn = make_fastdiv(p.tiles_n);
   p.div_ks = make_fastdiv(ksplit);
+  {
+    const char* gm_s = getenv("SEMSEG_CONV_GM");   // read per call (A/B): 0/1 = row-major tile order
+    p.gm = gm_s ? atoi(gm_s) : 8;
+  }
   const int grid = p.full_tiles + (tiles - p.full_tiles) * ksplit;
   // buffer-load kernels need 1x1 / 3x3 taps, split points on chunk boundaries and < 2 GB operands
 #ifndef CONV_BUFLOAD
@@ -1916,6 +1962,13 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   const int tiles = a.tiles_co * a.tiles_ci * RS;
   const int ksteps = (M + 31) / 32;
   a.batch = batch; a.x_bs = x_bs; a.dy_bs = dy_bs;
+  // Workgroup order inside a K slice (direct-to-LDS kernel): taps fastest, then the operand dimension with FEWER
+  // tiles, so that the ~64 workgroups an XCD holds at a time touch few distinct operand blocks.  Measured per shape
+  // with FETCH_SIZE (scripts/wgrad_traffic.py): cls.0 34.2 -> 6.1 GB, aux.0 1.57 -> 0.67 GB,
+  // layer4 3x3 1.25 -> 0.81 GB, layer4 1x1 0.9 -> 0.64 GB per launch; 2.79x -> 1.4x the algorithmic bytes over the
+  // step's launch mix.  SEMSEG_WGRAD_ORDER = 0|1|2 forces one order (read per call: tuning scripts).
+  const char* order_s = getenv("SEMSEG_WGRAD_ORDER");
+  a.order = order_s ? atoi(order_s) : (RS > 1 ? 1 : (a.tiles_co < a.tiles_ci ? 1 : 0));
   scratch_floats /= batch;   // every batch item owns its own slab set
   // Direct-to-LDS variants of the 128 x 128 kernel (1..5 = K-step / ring depth / residency; 0 = register-staged
   // kernel).  They need byte offsets below 2^31 for both operands.
