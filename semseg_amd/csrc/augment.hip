@@ -47,7 +47,7 @@ __device__ __forceinline__ View src_view(const Op& o) {
 // pixel (y, x) of the virtual image, channel c.  The planner guarantees (y, x) is inside the ROI; the clamp only
 // keeps a planner bug from reading outside the arena.
 __device__ __forceinline__ size_t roi_index(const View& v, int y, int x) {
-  const int ly = min(max(y - v.y0, 0), v.h - 1), lx = min(max(x - v.x0, 0), v.w - 1);
+  const int ly = max(min(y - v.y0, v.h - 1), 0), lx = max(min(x - v.x0, v.w - 1), 0);
   return (size_t)ly * v.w + lx;
 }
 __device__ __forceinline__ float px(const View& v, int y, int x, int c) {

@@ -100,4 +100,8 @@ class DeviceCollate(object):
     def __call__(self, samples):
         images = [s[0] for s in samples]
         labels = [s[1] for s in samples]
-        return self.compose.batch(images, labels, stack=True, device=self.device)
+        x, y = self.compose.batch(images, labels, stack=True, device=self.device)
+        if isinstance(x, list):
+            raise RuntimeError("DeviceCollate: the chain must end in ToTensor() and give every sample the same size "
+                               "(a Crop), as tool/train.py:194-201 does; got per-sample outputs\n")
+        return x, y

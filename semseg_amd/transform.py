@@ -29,7 +29,7 @@ from . import ops
 from ._lib import lib
 
 MAX_MAPS = 6
-K_NONE, K_RESIZE, K_ROTATE, K_BLUR, K_GATHER = 0, 1, 2, 3, 4
+K_RESIZE, K_ROTATE, K_BLUR, K_GATHER = 1, 2, 3, 4     # SEMSEG_AUG_* (0 = no op in this round)
 
 
 class AugMap(ctypes.Structure):
