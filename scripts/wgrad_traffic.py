@@ -84,8 +84,27 @@ def digest(fetch_csv, write_csv=None):
     print("count-weighted: algorithmic %.1f MB, moved %.1f MB per launch-mix step; ratio %.2f" % (tot_a, tot_t, tot_t / tot_a))
 
 
+def counters(path):
+    """per-shape table of every counter in a counter_collection.csv (second launch of each pair)"""
+    rows = {}
+    for r in csv.DictReader(open(path)):
+        if "conv_wgrad" not in r["Kernel_Name"]:
+            continue
+        rows.setdefault(int(r["Dispatch_Id"]), {}).setdefault(r["Counter_Name"], 0.0)
+        rows[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    ids = sorted(rows)
+    assert len(ids) == 2 * len(SHAPES), len(ids)
+    names = sorted({c for v in rows.values() for c in v})
+    print("%-28s " % "shape" + " ".join("%16s" % n[-16:] for n in names))
+    for i, sh in enumerate(SHAPES):
+        v = rows[ids[2 * i + 1]]
+        print("%-28s " % sh[0] + " ".join("%16.4g" % v.get(n, 0) for n in names))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "counters":
+        counters(sys.argv[2])
     else:
         digest(*sys.argv[2:4])
