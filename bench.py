@@ -136,6 +136,16 @@ def cpu_baseline(layers, classes, size, iters=2, arch="psp"):
                                                                iters)}
 
 
+def _tile_summary():
+    """forward / data-gradient launches per tile width chosen by semseg_amd.ops (first warm-up step)"""
+    from semseg_amd import ops
+    out = {}
+    for key, t in ops.TILE_CHOICE.items():
+        k = "%s_128x%d" % (key[0], t)
+        out[k] = out.get(k, 0) + 1
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,7 +251,8 @@ def main():
                                    "train step fwd+loss+bwd+SGD, SyncBN, random-init weights"
                                    % ("P" if args.arch == "psp" else "A", args.layers, args.size, args.size,
                                       args.classes, args.global_batch, B),
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "tile_widths_measured_in_warmup": _tile_summary()},
             "final_main_loss": round(loss_val, 5),
             "algorithmic_tflop_per_step": round(step_flops / 1e12, 3),
             "whole_step_frac_of_f32_mfma_peak": round(step_flops / (dt / args.steps) / 1e12 / world /

@@ -64,6 +64,43 @@ class PackedConv:
 
 NSLOT = 8  # replicas of every fp64 statistics vector (see include/semseg_hip.h)
 
+# ---------------------------------------------------------------------------------------------
+# Tile-width choice for the forward / data-gradient kernel, measured per shape.
+# Layers with >= 128 output columns can run 128 x 128 or 128 x 64 tiles on the same packed panels.  Which one wins is
+# decided by residency-round quantisation and K-split overhead, not by the tile's own efficiency: at bs 16 the 900-tile
+# layer3 launches (1.76 rounds of 512 resident 128 x 128 workgroups) are 5-10 % faster with 128 x 64 tiles while
+# layer4 / cls.0 are not; at per-GPU batch 2-8 nearly every layer prefers the narrow tile to a 2-4 way K split
+# (DESIGN.md section 8.2 item 8).  No static rule covered batch 2 / 4 / 8 / 16 and 473 / 713 inputs, so the first
+# call of each (direction, shape) times both widths on the real operands (plain epilogue, scratch output, device idle)
+# and keeps 64 only when it wins by >= 3 %.  SEMSEG_TILE_TUNE=0 disables it (always 128); TILE_CHOICE is the table.
+# ---------------------------------------------------------------------------------------------
+import os as _os
+
+TILE_TUNE = _os.environ.get("SEMSEG_TILE_TUNE", "1") != "0"
+TILE_CHOICE = {}
+
+
+def _tuned_tile(key, out_floats, launch):
+    """launch(tile, out_tensor) -> return code of a side-effect-free launch of this shape."""
+    t = TILE_CHOICE.get(key)
+    if t is not None:
+        return t
+    tmp = torch.empty(out_floats, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    best = {}
+    for tile in (128, 64, 128, 64):
+        _ck(launch(tile, tmp), "tile tuning")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            _ck(launch(tile, tmp), "tile tuning")
+        e1.record()
+        e1.synchronize()
+        best[tile] = min(best.get(tile, 1e30), e0.elapsed_time(e1))
+    t = 64 if best[64] < 0.97 * best[128] else 128
+    TILE_CHOICE[key] = t
+    return t
+
 
 def _scr(scratch):
     return (None, 0) if scratch is None else (scratch.data_ptr(), scratch.numel())
@@ -78,17 +115,34 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
              nslot=1, scratch=None, scale=None, relu=False):
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
+    tile = pk.tile_fwd
+    if tile == 128 and TILE_TUNE:
+        tile = _tuned_tile(("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil, ldx, ldy), N * Ho * Wo * ldy,
+                           lambda t, out: lib.semseg_conv_fwd(
+                               _p(x), ldx, _p(pk.w_fwd), _p(out), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
+                               pad, dil, None, None, 0, None, 0, None, 1, t, *_scr(scratch), _stream()))
     _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
                             pk.R, pk.S, stride, pad, dil, _p(bias), _p(scale), int(relu), _p(add), ldadd,
-                            _p(stats), nslot, pk.tile_fwd, *_scr(scratch), _stream()), "conv_fwd")
+                            _p(stats), nslot, tile, *_scr(scratch), _stream()), "conv_fwd")
     return Ho, Wo
+
+
+def _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch):
+    tile = pk.tile_dgrad
+    if tile == 128 and TILE_TUNE:
+        tile = _tuned_tile(("dgrad", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil, lddy, lddx), N * H * W * lddx,
+                           lambda t, out: lib.semseg_conv_dgrad(
+                               _p(dy), lddy, _p(pk.w_dgrad), _p(out), lddx, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S,
+                               stride, pad, dil, None, 0, t, *_scr(scratch), _stream()))
+    return tile
 
 
 def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldadd=0, scratch=None):
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
+    tile = _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch)
     _ck(lib.semseg_conv_dgrad(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo,
-                              pk.Co, pk.R, pk.S, stride, pad, dil, _p(add), ldadd, pk.tile_dgrad,
+                              pk.Co, pk.R, pk.S, stride, pad, dil, _p(add), ldadd, tile,
                               *_scr(scratch), _stream()), "conv_dgrad")
 
 
@@ -100,8 +154,9 @@ def conv_dgrad_bnreduce(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, act, 
     Wo = conv_out(W, pk.S, stride, pad, dil)
     b0 = bns[0]
     b1 = bns[1] if len(bns) > 1 else (None, 0, None, None, None)
+    tile = _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch)
     _ck(lib.semseg_conv_dgrad_bnreduce(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R,
-                                       pk.S, stride, pad, dil, _p(add), ldadd, pk.tile_dgrad, len(bns), _p(act), ldact,
+                                       pk.S, stride, pad, dil, _p(add), ldadd, tile, len(bns), _p(act), ldact,
                                        _p(b0[0]), b0[1], _p(b0[2]), _p(b0[3]), _p(b0[4]),
                                        _p(b1[0]), b1[1], _p(b1[2]), _p(b1[3]), _p(b1[4]), nslot, *_scr(scratch),
                                        _stream()), "conv_dgrad_bnreduce")
