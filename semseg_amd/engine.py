@@ -328,7 +328,8 @@ class Engine:
         if out is None:
             ld = cl.Co if cl.Co % 64 == 0 else ops.roundup(cl.Co, 128)
             out = self.act(x.N, Ho, Wo, cl.Co, ld=ld, tag="conv")
-        ev = self._t0("conv_igemm_kernel<128,%d,false,%d>(+splitk_epilogue)" % (cl.pk.tile_fwd, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
+        tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld)
+        ev = self._t0("conv_igemm_kernel<128,%d,false,%d>(+splitk_epilogue)" % (tile, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
         if fold is not None:
             sc, sh, relu, res = fold
             ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
@@ -394,7 +395,8 @@ class Engine:
             bs = x.bnsrc
             fuse = (self.fuse_bnr and last and bs is not None and x.C % 4 == 0 and x.ld % 4 == 0 and
                     all(yk.ld % 4 == 0 for yk, _ in bs["bns"]))
-            ev = self._t0("conv_igemm_kernel<128,%d,true,%d>(+splitk_epilogue)" % (cl.pk.tile_dgrad, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), flops)
+            tile = ops.chosen_tile("dgrad", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, y.ld, x.ld)
+            ev = self._t0("conv_igemm_kernel<128,%d,true,%d>(+splitk_epilogue)" % (tile, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), flops)
             if fuse:
                 ops.conv_dgrad_bnreduce(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
                                         x.data if bs["relu"] else None, x.ld,

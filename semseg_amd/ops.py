@@ -127,6 +127,12 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
     return Ho, Wo
 
 
+def chosen_tile(kind, pk, N, H, W, stride, pad, dil, ld_in, ld_out):
+    """Tile width the (already measured) shape runs with; kind "fwd" | "dgrad".  For kernel-family labels."""
+    dflt = pk.tile_fwd if kind == "fwd" else pk.tile_dgrad
+    return TILE_CHOICE.get((kind, N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil, ld_in, ld_out), dflt)
+
+
 def _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch):
     tile = pk.tile_dgrad
     if tile == 128 and TILE_TUNE:
