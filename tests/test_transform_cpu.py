@@ -248,3 +248,15 @@ def test_stage_grouping():
     c = T.Compose([T.RGB2BGR()] * 8 + [T.ToTensor()])
     sg = T._stages(c.plan(10, 10), 10, 10)
     assert [len(s["maps"]) for s in sg] == [6, 2] and [s["final"] for s in sg] == [False, True]
+
+
+def test_f1_and_f3_restatements_of_cv2_resize_agree():
+    """oracle/test_pipeline.py (test-time pipeline, float64 torch bilinear) and oracle/cv2_restated.py (float32 two-pass,
+    OpenCV's coefficient rounding) restate the same cv2.resize(INTER_LINEAR) call: they must agree to float32 noise."""
+    from oracle import test_pipeline as tp
+    rng = np.random.default_rng(7)
+    img = (rng.random((61, 83, 3)) * 255).astype(np.float32)
+    for (nh, nw) in [(61, 83), (92, 125), (30, 41), (123, 166)]:
+        a = tp.cv2_resize_linear(img, nw, nh)
+        b = ocv.resize(img, (nw, nh), interpolation=ocv.INTER_LINEAR)
+        assert a.shape == b.shape and np.abs(a - b).max() < 2e-3
