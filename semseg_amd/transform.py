@@ -407,6 +407,20 @@ class Compose(object):
             t.plan(st)
         return st
 
+    def schedule(self, sizes):
+        """Host-only part of `batch`: draw every sample's parameters (sample order = the reference's draw order), group
+        the plan into stages and propagate the needed regions from the last stage to the first.  -> (plans, chains);
+        each stage dict carries dst_roi (region it writes) and src_need (region of its input it reads)."""
+        plans = [self.plan(h, w) for (h, w) in sizes]
+        chains = [_stages(p, h, w) for p, (h, w) in zip(plans, sizes)]
+        for ch in chains:
+            roi = (0, 0, ch[-1]["out_h"], ch[-1]["out_w"])
+            for stg in reversed(ch):
+                stg["dst_roi"] = roi
+                roi = _need(stg, roi)
+                stg["src_need"] = roi
+        return plans, chains
+
     def __call__(self, image, label):
         imgs, labs = self.batch([image], [label], stack=False)
         return imgs[0], labs[0]
@@ -418,16 +432,7 @@ class Compose(object):
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         B = len(images)
         metas = [_as_source(im, lb) for im, lb in zip(images, labels)]
-        plans = [self.plan(h, w) for (_, h, w) in metas]              # sample order = the reference's draw order
-        chains = [_stages(p, h, w) for p, (_, h, w) in zip(plans, metas)]
-
-        # needed regions, last stage to first
-        for ch in chains:
-            roi = (0, 0, ch[-1]["out_h"], ch[-1]["out_w"])
-            for stg in reversed(ch):
-                stg["dst_roi"] = roi
-                roi = _need(stg, roi)
-                stg["src_need"] = roi
+        plans, chains = self.schedule([(h, w) for (_, h, w) in metas])
 
         # one arena: host-resident sources first (one H2D copy), then the intermediate regions
         off = 0

@@ -260,3 +260,52 @@ def test_f1_and_f3_restatements_of_cv2_resize_agree():
         a = tp.cv2_resize_linear(img, nw, nh)
         b = ocv.resize(img, (nw, nh), interpolation=ocv.INTER_LINEAR)
         assert a.shape == b.shape and np.abs(a - b).max() < 2e-3
+
+
+# ---------------- the host schedule executed on the CPU, region by region ----------------
+def _emulate(ops, img, lab, seed):
+    from semseg_amd import transform as T
+    import transform_emulator as em
+    chain_obj = tc.build_chain(T, ops)
+    random.seed(seed)
+    plans, chains = chain_obj.schedule([lab.shape])
+    return em.run_chain(plans[0], chains[0], img, lab)
+
+
+@pytest.mark.parametrize("name", sorted(tc.CASES))
+def test_schedule_reproduces_golden_on_cpu(name):
+    """stage grouping + index-map composition + needed regions: executing the schedule with every unmaterialised pixel
+    poisoned gives the reference's output bit for bit"""
+    H, W, ops, seeds = tc.CASES[name]
+    img, lab = tc.make_input(name, H, W)
+    for seed in seeds:
+        gi, gl = _emulate(ops, img, lab, seed)
+        assert np.array_equal(gl, GOLD["%s/%d/label" % (name, seed)]), (name, seed)
+        assert np.array_equal(gi, GOLD["%s/%d/image" % (name, seed)]), (name, seed)
+
+
+def test_schedule_random_chains_match_oracle():
+    """random sizes, crops, orders and seeds beyond the golden cases (property test of the region propagation)"""
+    rng = random.Random(11)
+    for trial in range(60):
+        H, W = rng.randint(24, 90), rng.randint(24, 90)
+        ch, cw = rng.randint(9, 70), rng.randint(9, 70)
+        geo = [("rand_scale", (0.5, 2.0), rng.choice([None, (0.7, 1.4)])),
+               ("rand_rotate", (-rng.uniform(5, 40), rng.uniform(5, 40)), tc.MEAN, 255, rng.choice([0.5, 1.0])),
+               ("rand_blur", rng.choice([3, 5, 7])), ("rand_hflip", 0.5), ("rand_vflip", 0.5),
+               ("crop", (ch, cw), rng.choice(["rand", "center"]), tc.MEAN, 255), ("swap_rb",),
+               ("resize", (rng.randint(16, 60), rng.randint(16, 60)))]
+        rng.shuffle(geo)
+        ops = geo[:rng.randint(1, len(geo))]
+        if rng.random() < 0.7:
+            ops = ops + [("to_tensor",)] + ([("normalize", tc.MEAN, rng.choice([tc.STD, None]))] if rng.random() < 0.7 else [])
+        img, lab = tc.make_input("r%d" % trial, H, W)
+        seed = rng.randint(0, 10 ** 6)
+        random.seed(seed)
+        try:
+            oi, ol = otf.run(ops, np.float32(img), lab.copy())
+        except AssertionError:
+            continue                                    # the drawn scale collapsed the image to nothing
+        gi, gl = _emulate(ops, img, lab, seed)
+        assert np.array_equal(gl, _np(ol)), (trial, ops)
+        assert np.array_equal(gi, _np(oi)), (trial, ops)
