@@ -3,7 +3,7 @@
   side  = every weight gradient on the side stream (Engine.side_all),
   hipri = dependent backward chain on a high-priority stream (Engine.hipri_main),
 interleaved over ROUNDS rounds.  python scripts/step_variants.py [batch] [rounds] [arch]"""
-import os, sys, time, itertools
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from semseg_amd.trainer import Trainer

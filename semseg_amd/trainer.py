@@ -12,7 +12,7 @@ import os
 
 import torch
 import torch.distributed as dist
-from torch import nn
+
 
 from . import ops
 from .engine import Engine
