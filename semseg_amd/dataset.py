@@ -18,30 +18,21 @@ import os
 import numpy as np
 from torch.utils.data import Dataset
 
-IMG_EXTENSIONS = ['.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.pgm']
-
-
-def is_image_file(filename):
-    return any(filename.lower().endswith(ext) for ext in IMG_EXTENSIONS)
-
-
 def make_dataset(split='train', data_root=None, data_list=None):
     """util/dataset.py:17-49: 'image label' pairs per line (one path per line for split == 'test')."""
-    assert split in ['train', 'val', 'test']
+    assert split in ('train', 'val', 'test')
     if not os.path.isfile(data_list):
-        raise RuntimeError("Image list file do not exist: " + data_list + "\n")
+        raise RuntimeError("no such image list file: %s\n" % data_list)
+    columns = 1 if split == 'test' else 2
     pairs = []
     with open(data_list) as f:
-        lines = f.readlines()
-    want = 1 if split == 'test' else 2
-    for line in lines:
-        line = line.strip()
-        parts = line.split(' ')
-        if len(parts) != want:
-            raise RuntimeError("Image list file read line error : " + line + "\n")
-        image_name = os.path.join(data_root, parts[0])
-        label_name = image_name if split == 'test' else os.path.join(data_root, parts[1])
-        pairs.append((image_name, label_name))
+        for raw in f:
+            fields = raw.strip().split(' ')
+            if len(fields) != columns:
+                raise RuntimeError("image list line does not have %d column(s): %r\n" % (columns, raw.strip()))
+            image_name = os.path.join(data_root, fields[0])
+            # test split: the label slot repeats the image path as a placeholder (dataset.py:33)
+            pairs.append((image_name, os.path.join(data_root, fields[1]) if columns == 2 else image_name))
     return pairs
 
 
@@ -83,7 +74,7 @@ class SemData(Dataset):
                 raise RuntimeError("label file is not 8-bit grey: " + label_path + "\n")
             label = np.zeros(image.shape[:2], dtype=np.uint8)
         if image.shape[0] != label.shape[0] or image.shape[1] != label.shape[1]:
-            raise RuntimeError("Image & label shape mismatch: " + image_path + " " + label_path + "\n")
+            raise RuntimeError("image and label sizes differ: %s %s\n" % (image_path, label_path))
         if self.transform is not None:
             image, label = self.transform(image, label)
         return image, label
