@@ -151,3 +151,22 @@ def test_rejects_bad_input():
         c(np.zeros((4, 5, 3), dtype=np.uint8), np.zeros((4, 6), dtype=np.uint8))       # shape mismatch (dataset.py:65-66)
     with pytest.raises(RuntimeError):
         c(np.zeros((4, 5, 3), dtype=np.float64), np.zeros((4, 5), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("ops", [[("rand_scale", (0.7, 1.6), None)],
+                                 [("rand_rotate", (-30, 30), tc.MEAN, 255, 1.0)],
+                                 [("rand_hflip", 1.0), ("rand_blur", 5)],
+                                 [("resize", (50, 41)), ("to_tensor",)],
+                                 [("swap_rb",)] * 8 + [("rand_scale", (1.2, 1.3), None), ("swap_rb",), ("to_tensor",)]],
+                         ids=["scale_only", "rotate_only", "flip_blur", "resize_tensor", "many_maps"])
+def test_chains_ending_in_a_resampling_stage(ops):
+    """no final gather (the last stage's region IS the result), > 6 index maps in a row, blur as the last stage"""
+    T = _T()
+    img, lab = tc.make_input("tail", 57, 66)
+    chain = tc.build_chain(T, ops)
+    for seed in (1, 2, 3):
+        random.seed(seed)
+        gi, gl = chain(img, lab)
+        random.seed(seed)
+        oi, ol = otf.run(ops, np.float32(img), lab.copy())
+        assert np.array_equal(_np(gi), _np(oi)) and np.array_equal(_np(gl), _np(ol)), seed
