@@ -33,17 +33,21 @@ def run(world, rank, steps=2, bucket_mb=8):
     dev = torch.device("cuda", 0)
     m = make_model().to(dev).train()
     tr = Trainer(m, base_lr=0.01, momentum=0.9, weight_decay=1e-4, bucket_mb=bucket_mb, sync_bn=True)
-    x, y = data(4)
-    per = 4 // world
+    gb = int(os.environ.get("GLOBAL_BATCH", "4"))
+    x, y = data(gb)
+    per = gb // world
     xs, ys = x[rank * per:(rank + 1) * per].to(dev), y[rank * per:(rank + 1) * per].to(dev)
     losses = []
+    w_first = None
     for it in range(steps):
         _, ml, al = tr.step(xs, ys, lr=0.01)
         losses.append((float(ml.item()), float(al.item())))
+        if it == 0:
+            w_first = tr.flat_w.cpu().numpy()
     torch.cuda.synchronize()
     sd = m.state_dict()
     return np.array(losses), tr.flat_w.cpu().numpy(), sd["layer0.1.running_var"].cpu().numpy(), \
-        sd["cls.1.running_mean"].cpu().numpy()
+        sd["cls.1.running_mean"].cpu().numpy(), w_first
 
 
 if __name__ == "__main__":
@@ -52,8 +56,8 @@ if __name__ == "__main__":
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    losses, w, rv, rm = run(world, rank)
-    np.savez(os.path.join(out, "rank%d_of%d.npz" % (rank, world)), losses=losses, w=w, rv=rv, rm=rm)
+    losses, w, rv, rm, w1 = run(world, rank, steps=int(os.environ.get("STEPS", "2")))
+    np.savez(os.path.join(out, "rank%d_of%d.npz" % (rank, world)), losses=losses, w=w, rv=rv, rm=rm, w1=w1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,6 +25,35 @@ def _free_port():
     return p
 
 
+def test_eight_ranks_equal_single_process(report):
+    """8 ranks x 1 image with SyncBN + gradient all-reduce == one process with 8 images
+    (all eight ranks share the test box's single GPU through gloo; the code path is the one RCCL takes)."""
+    tmp = tempfile.mkdtemp(prefix="semseg_dist8_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GLOBAL_BATCH="8")
+    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+    subprocess.check_call([sys.executable, worker, tmp], env=env, timeout=600)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, tmp],
+                          env=env, timeout=900)
+    one = np.load(os.path.join(tmp, "rank0_of1.npz"))
+    ranks = [np.load(os.path.join(tmp, "rank%d_of8.npz" % r)) for r in range(8)]
+    for r in ranks[1:]:
+        assert np.array_equal(ranks[0]["w"], r["w"]) and np.array_equal(ranks[0]["rv"], r["rv"])
+    l8 = sum(r["losses"] for r in ranks) / 8.0
+    e_step = np.abs(l8 - one["losses"]) / np.abs(one["losses"])
+    e_w1 = np.abs(ranks[0]["w1"] - one["w1"]).max() / np.abs(one["w1"]).max()
+    e_w = np.abs(ranks[0]["w"] - one["w"]).max() / np.abs(one["w"]).max()
+    e_rv = np.abs(ranks[0]["rv"] - one["rv"]).max() / np.abs(one["rv"]).max()
+    e_rm = np.abs(ranks[0]["rm"] - one["rm"]).max() / np.abs(one["rm"]).max()
+    report("8-rank DP vs single process: losses per step (main, aux) %s; weights after 1 step %.2e, after 2 steps %.2e; "
+           "running_var %.2e running_mean %.2e" % (np.array2string(e_step, precision=2), e_w1, e_w, e_rv, e_rm))
+    # step 1 is the equivalence proper: the forward (SyncBN over 8 x 1 image) and the update (gradient all-reduce / 8)
+    # agree to fp32 summation noise.  The second step starts from weights that differ by that noise, and this 57 x 57
+    # toy net amplifies it (ReLU-mask flips) - measured 3.8e-4 in the loss, 3.9e-3 in the weights: loose bounds only.
+    assert e_step[0].max() < 1e-6 and e_w1 < 2e-4
+    assert e_step[1].max() < 5e-3 and e_w < 2e-2 and e_rv < 1e-4 and e_rm < 1e-2
+
+
 def test_two_ranks_equal_single_process(report):
     tmp = tempfile.mkdtemp(prefix="semseg_dist_")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
