@@ -80,13 +80,13 @@ TILE_TUNE = _os.environ.get("SEMSEG_TILE_TUNE", "1") != "0"
 TILE_CHOICE = {}
 
 
-def _tuned_tile(key, out_floats, launch, device):
+def _tuned_tile(key, out_floats, launch):
     """launch(tile, out_tensor) -> return code of a side-effect-free launch of this shape."""
     t = TILE_CHOICE.get(key)
     if t is not None:
         return t
-    tmp = torch.empty(out_floats, dtype=torch.float32, device=device)
-    torch.cuda.synchronize(device)
+    tmp = torch.empty(out_floats, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     best = {}
     for tile in (128, 64, 128, 64):
         _ck(launch(tile, tmp), "tile tuning")
@@ -120,7 +120,7 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
         tile = _tuned_tile(("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil, ldx, ldy), N * Ho * Wo * ldy,
                            lambda t, out: lib.semseg_conv_fwd(
                                _p(x), ldx, _p(pk.w_fwd), _p(out), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
-                               pad, dil, None, None, 0, None, 0, None, 1, t, *_scr(scratch), _stream()), x.device)
+                               pad, dil, None, None, 0, None, 0, None, 1, t, *_scr(scratch), _stream()))
     _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
                             pk.R, pk.S, stride, pad, dil, _p(bias), _p(scale), int(relu), _p(add), ldadd,
                             _p(stats), nslot, tile, *_scr(scratch), _stream()), "conv_fwd")
@@ -139,7 +139,7 @@ def _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch):
         tile = _tuned_tile(("dgrad", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil, lddy, lddx), N * H * W * lddx,
                            lambda t, out: lib.semseg_conv_dgrad(
                                _p(dy), lddy, _p(pk.w_dgrad), _p(out), lddx, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S,
-                               stride, pad, dil, None, 0, t, *_scr(scratch), _stream()), dy.device)
+                               stride, pad, dil, None, 0, t, *_scr(scratch), _stream()))
     return tile
 
 
