@@ -1,5 +1,5 @@
-"""Interleaved A/B of the forward / data-gradient kernel: SEMSEG_CONV_DMA = 0 (register-staged) vs 1 (direct-to-LDS
-2-stage ring) on the PSPNet-101 bs16 473^2 shapes.  python scripts/conv_variants.py [bs] [rounds]"""
+"""Interleaved A/B of a per-launch environment switch of the forward / data-gradient kernel (VAR, default
+SEMSEG_CONV_TL: two-level accumulation rule) on the PSPNet-101 bs16 473^2 shapes.  python scripts/conv_variants.py [bs] [rounds]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ from semseg_amd import ops
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 VARS = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
-VAR = os.environ.get("VAR", "SEMSEG_CONV_DMA")    # e.g. VAR=SEMSEG_CONV_TL to A/B the two-level accumulation rule
+VAR = os.environ.get("VAR", "SEMSEG_CONV_TL")    # e.g. VAR=SEMSEG_CONV_TL to A/B the two-level accumulation rule
 SHAPES = [  # name, H, Ci, Co, k, stride, pad, dil, count(R101)
     ("stem3 64->128 3x3 @237", 237, 64, 128, 3, 1, 1, 1, 1),
     ("l1 conv3 64->256 1x1 @119", 119, 64, 256, 1, 1, 0, 1, 3),

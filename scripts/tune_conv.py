@@ -5,12 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "semseg_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_variants")
 VARIANTS = {   # last used set; earlier sets are listed in DESIGN.md section 8.1
-    "occ2_a": [],
-    "occ3_1x1_a": ["-DCONV_OCC_1X1=3"],
-    "occ2_b": [],
-    "occ3_1x1_b": ["-DCONV_OCC_1X1=3"],
+    "base_a": [],      # add {"name": ["-DKNOB=value"]} entries for the experiment at hand; the product source carries
+    "base_b": [],      # no knobs any more (round 3), so a knob lives only as long as its experiment
 }
-SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "infer.hip", "optim.hip"]
+SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "infer.hip", "optim.hip", "augment.hip"]
 if sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     procs = []

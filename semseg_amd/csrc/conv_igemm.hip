@@ -23,37 +23,7 @@ namespace {
 constexpr int BK = 32;   // K-step (floats)
 constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 conflict-free
 
-// tuning knobs (scripts/tune_conv.py builds variants with -D...)
-#ifndef WGRAD_ABL
-#define WGRAD_ABL 0
-#endif
-#ifndef WGRAD_SMALL_TILES
-#define WGRAD_SMALL_TILES 1
-#endif
-#ifndef WGRAD_XCD
-#define WGRAD_XCD 1
-#endif
-#ifndef WGRAD_PF_KP
-#define WGRAD_PF_KP 3
-#endif
-#ifndef CONV_TWO_LEVEL
-#define CONV_TWO_LEVEL 1
-#endif
-#ifndef CONV_OCC
-#define CONV_OCC 2
-#endif
-#ifndef CONV_OCC_1X1
-#define CONV_OCC_1X1 2
-#endif
-#ifndef CONV_DBUF
-#define CONV_DBUF 0
-#endif
-#ifndef CONV_PRIO
-#define CONV_PRIO 0
-#endif
-#ifndef CONV_ABL   // ablation (timing only, results wrong): 1 no global prefetch, 2 +no LDS store/barrier, 3 +no LDS read
-#define CONV_ABL 0
-#endif
+constexpr int CONV_OCC = 2;   // resident workgroups per CU the forward / data-gradient kernel is compiled for
 
 // exact n / d for 0 <= n < 2^31 by one 64-bit multiply: q = (n * mul) >> sh
 struct FastDiv {
@@ -75,15 +45,6 @@ __device__ __forceinline__ int fdiv(int n, FastDiv f) {
 // the load: a select on the loaded value would make the compiler wait for the load before the MFMA
 // block (measured: -13 % on every conv).
 __device__ __attribute__((aligned(16))) float g_zero_line[32] = {0};
-
-// 16 bytes per lane from a raw buffer straight into LDS at (wave-uniform lds + lane * 16); voffset per lane, soffset
-// scalar.  The builtin only exists for the device pass: on the host pass of a TEMPLATE kernel it silently suppresses the
-// launch stub (ROCm 7.2), hence the guard.
-__device__ __forceinline__ void dma16_to_lds_s(__amdgpu_buffer_rsrc_t rsrc, float* lds, unsigned voffset, int soffset) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, soffset, 0, 0);
-#endif
-}
 
 struct ConvArgs {
   const float* x;   // A source: activations (fwd) or output-gradient (dgrad), NHWC
@@ -368,7 +329,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
 // carry an out-of-range offset, which the buffer unit returns as 0) plus one scalar offset per K-step —
 // no per-K-step address VALU between the MFMAs at all.
 template <int BM, int BN, bool TR, int RS_T, bool TL>
-__global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OCC) void conv_igemm_kernel(const ConvArgs pin) {
+__global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const ConvArgs pin) {
   ConvArgs p = pin;
   if (p.batch > 1) {
     const long long bz = blockIdx.y;
@@ -383,11 +344,8 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
   constexpr int MREP = 2, NREP = BN / 64;
   constexpr int A_PER = BM / RSTEP, B_PER = BN / RSTEP;
   constexpr int STAGE = (BM + BN) * LDK;
-#ifndef CONV_LDSPAD
-#define CONV_LDSPAD 0
-#endif
   constexpr int EPI = (NT / 64) * 64 * LDK;  // per-wave transposition slabs of the epilogue
-  constexpr int SMEM_BASE = ((CONV_DBUF ? 2 : 1) * STAGE > EPI ? (CONV_DBUF ? 2 : 1) * STAGE : EPI) + CONV_LDSPAD;
+  constexpr int SMEM_BASE = STAGE > EPI ? STAGE : EPI;
   constexpr int RED2_F = TR ? 2 * (BM / 64) * BN * 2 * 2 : 0;   // fp64 column sums of the fused BatchNorm-backward reduction
   constexpr int SMEM_F = SMEM_BASE + RED2_F;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
@@ -399,17 +357,6 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-#ifndef CONV_STAGGER
-#define CONV_STAGGER 0
-#endif
-#if CONV_STAGGER
-  // co-resident workgroups start in lockstep and then hit their prologue / epilogue phases together;
-  // a one-time skew of the first residency round spreads those phases
-  if (blockIdx.x < 768) {
-    const int slot = (blockIdx.x >> 8) % 3;
-    for (int d = 0; d < slot * CONV_STAGGER; ++d) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   int ks = 0, tile;
   bool split = false;
   if ((int)blockIdx.x < p.full_tiles) {
@@ -526,7 +473,7 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
   // (rms 2.3e-6 at K = 36864, 7x a blocked CPU sum).  Every ~1024 K the chain is flushed into a second
   // accumulator set, which bounds the chain length.  TL is set by the launcher whenever K > 576 (240 VGPRs on the
   // 128 x 128 tile, still occupancy 2); shorter reductions keep the leaner kernel.
-  constexpr bool TWO_LEVEL = CONV_TWO_LEVEL && TL;
+  constexpr bool TWO_LEVEL = TL;
   f32x16 acc2[TWO_LEVEL ? MREP : 1][TWO_LEVEL ? NREP : 1];
   if constexpr (TWO_LEVEL) {
 #pragma unroll
@@ -561,18 +508,9 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
   // do_pf: issue the next tile's global loads after the first MFMA group, so their address VALU and
   // issue slots hide in the shadow of this wave's own MFMAs instead of preceding them
   auto compute = [&](const float* A_, const float* B_, auto&& issue_next) {
-#if CONV_PRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int k8 = 0; k8 < 4; ++k8) {
       f32x4 a[MREP], b[NREP];
-#if CONV_ABL == 3
-#pragma unroll
-      for (int i = 0; i < MREP; ++i) { a[i] = ra[i]; asm volatile("" : "+v"(a[i])); }
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) { b[j] = rb[j]; asm volatile("" : "+v"(b[j])); }
-#else
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
         a[i] = *reinterpret_cast<const f32x4*>(
@@ -581,7 +519,6 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
       for (int j = 0; j < NREP; ++j)
         b[j] = *reinterpret_cast<const f32x4*>(
             &B_[(wn * (BN / 2) + j * 32 + l31) * LDK + k8 * 8 + lhi * 4]);
-#endif
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -591,9 +528,6 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
       if (k8 == 0) issue_next();
     }
-#if CONV_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   };
 
   if constexpr (RS_T > 0) {
@@ -601,9 +535,6 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
     constexpr unsigned OOB = 0x80000000u;          // >= num_records: the buffer unit returns 0
     const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x80000000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x80000000, 0x00020000);
-#ifndef CONV_VOFF_ONFLY
-#define CONV_VOFF_ONFLY 1
-#endif
     // per-tap byte offsets (uniform -> SGPRs)
     int toffs[RS_T];
 #pragma unroll
@@ -615,18 +546,9 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
         toffs[t] = -(((r * p.dil) / p.stride) * p.Win + (s_ * p.dil) / p.stride) * p.ldx * 4;
     }
     unsigned voffB[B_PER];
-#if CONV_VOFF_ONFLY
     unsigned baseA[A_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) baseA[i] = (unsigned)(a_base[i] * 4);
-#else
-    unsigned voffA[A_PER][RS_T];
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i)
-#pragma unroll
-      for (int t = 0; t < RS_T; ++t)
-        voffA[i][t] = ((a_mask[i] >> t) & 1u) ? (unsigned)(a_base[i] * 4 + toffs[t]) : OOB;
-#endif
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
       voffB[i] = (unsigned)(((size_t)(n0 + lrow + RSTEP * i) * wK + kq * 4) * 4);
@@ -637,11 +559,7 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
       const int so_b = (c * RS_T + t) * (BK * 4);
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) {
-#if CONV_VOFF_ONFLY
         const unsigned vo = ((a_mask[i] >> t) & 1u) ? baseA[i] + (unsigned)toffs[t] : OOB;
-#else
-        const unsigned vo = voffA[i][t];
-#endif
         ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, vo, so_a, 0));
       }
 #pragma unroll
@@ -679,30 +597,6 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
     }
   } else {
   prefetch(kt0);
-#if CONV_ABL
-  stage_store(As, Bs);
-  __syncthreads();
-  for (int kt = kt0; kt < KT; ++kt) {
-#if CONV_ABL == 1
-    stage_store(As, Bs);
-    __syncthreads();
-#endif
-    compute(As, Bs, [] {});
-#if CONV_ABL == 1
-    __syncthreads();
-#endif
-  }
-#elif CONV_DBUF
-  stage_store(smem + (kt0 & 1) * STAGE, smem + (kt0 & 1) * STAGE + BM * LDK);
-  __syncthreads();
-  for (int kt = kt0; kt < KT; ++kt) {
-    float* cA = smem + (kt & 1) * STAGE;
-    float* nA = smem + ((kt + 1) & 1) * STAGE;
-    compute(cA, cA + BM * LDK, [&] { if (kt + 1 < KT) prefetch(kt + 1); });
-    if (kt + 1 < KT) stage_store(nA, nA + BM * LDK);
-    __syncthreads();
-  }
-#else
   for (int kt = kt0; kt < KT; ++kt) {
     stage_store(As, Bs);
     __syncthreads();
@@ -710,7 +604,6 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
     __syncthreads();
     if (((kt - kt0) & 15) == 15) flush();
   }
-#endif
   }  // RS_T == 0
   if constexpr (TWO_LEVEL) {
 #pragma unroll
@@ -722,245 +615,6 @@ __global__ __launch_bounds__(BM * 2, (RS_T == 1 && !TL) ? CONV_OCC_1X1 : CONV_OC
   }
 
   conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m, reinterpret_cast<double*>(smem + SMEM_BASE));
-}
-
-// ------------------------------------------------------------------------------------------
-// Forward / data-gradient, direct-to-LDS variant (1x1 and 3x3 taps, 128-row tiles).  Same gather as the
-// buffer-load path above (per-(row, tap) byte offsets, out-of-range offsets for padding taps and rows past M,
-// which the buffer unit turns into zeros), but the 16-byte pieces go straight into LDS with
-// `buffer_load_dwordx4 ... lds` — no staging registers, no ds_write pass — into a 2-stage ring with ONE raw
-// s_barrier per K-step.  An LDS-DMA wave instruction writes 1 KiB lane-linearly = 8 K-contiguous rows of 128 B, so
-// the rows cannot be padded; bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the
-// 16-byte chunk index with ((row >> 1) & 7), applied on the SOURCE side (which chunk a lane fetches) and again on
-// the read side (cdna_hip_programming.md, rule 21): the 16 rows of a ds_read_b128 lane group then hit 16 different
-// 16-byte slots of the 256-byte bank row.
-// ------------------------------------------------------------------------------------------
-template <int BN, bool TR, int RS_T, bool TL>
-__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const ConvArgs pin) {
-  constexpr int BM = 128;
-  ConvArgs p = pin;
-  if (p.batch > 1) {
-    const long long bz = blockIdx.y;
-    p.x += bz * p.x_bs;
-    p.w += bz * p.w_bs;
-    p.y += bz * p.y_bs;
-    if (p.add) p.add += bz * p.add_bs;
-  }
-  constexpr int MREP = 2, NREP = BN / 64;
-  constexpr int A_PER = 4, B_PER = BN / 32;      // DMA instructions per wave per K-step (8 rows each)
-  constexpr int STAGE = (BM + BN) * BK;          // floats per ring slot, rows unpadded
-  constexpr int EPI = 4 * 64 * LDK;
-  constexpr int SMEM_F = 2 * STAGE > EPI ? 2 * STAGE : EPI;
-  constexpr unsigned OOB = 0x80000000u;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  int ks = 0, tile;
-  bool split = false;
-  if ((int)blockIdx.x < p.full_tiles) {
-    tile = xcd_remap(blockIdx.x, p.full_tiles);
-  } else {
-    const int u = xcd_remap(blockIdx.x - p.full_tiles, gridDim.x - p.full_tiles);
-    const int uq = fdiv(u, p.div_ks);
-    ks = u - uq * p.ksplit;
-    tile = p.full_tiles + uq;
-    split = p.ksplit > 1;
-  }
-  int tile_m, tile_n;
-  decode_tile(p, tile, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int nchunk = p.Kc / BK;
-  const int KT_all = RS_T * nchunk;
-  const size_t wK = (size_t)KT_all * BK;
-  const int kt0 = split ? ks * p.kt_per : 0;
-  const int KT = split ? min(KT_all, kt0 + p.kt_per) : KT_all;
-
-  // ---- DMA assignment: instruction i of this wave covers tile rows wave*32 + i*8 + (lane >> 3) (A) and
-  // wave*(BN/4) + i*8 + (lane >> 3) (B); lane & 7 is the LDS chunk position, which holds the source chunk
-  // (lane & 7) ^ ((row >> 1) & 7).  (row >> 1) & 7 = (4*i + (lane >> 4)) & 7 for both operands.
-  const int rsub = lane >> 3;
-  unsigned baseA[A_PER], maskA[A_PER];
-#pragma unroll
-  for (int i = 0; i < A_PER; ++i) {
-    const int m = m0 + wave * 32 + i * 8 + rsub;
-    const bool rok = m < p.M;
-    const int mm = rok ? m : 0;
-    const int hw = p.Hout * p.Wout;
-    const int n = fdiv(mm, p.div_hw);
-    const int rem = mm - n * hw;
-    const int oh = fdiv(rem, p.div_w);
-    const int ow = rem - oh * p.Wout;
-    unsigned mask = 0;
-    int bh, bw;
-    if (!TR) {
-      bh = oh * p.stride - p.pad;
-      bw = ow * p.stride - p.pad;
-    } else {
-      bh = (oh + p.pad) / p.stride;
-      bw = (ow + p.pad) / p.stride;
-    }
-    for (int r = 0; r < p.R; ++r)
-      for (int s_ = 0; s_ < p.S; ++s_) {
-        bool ok = rok;
-        int ih, iw;
-        if (!TR) {
-          ih = bh + r * p.dil;
-          iw = bw + s_ * p.dil;
-        } else {
-          const int rd = r * p.dil, sd = s_ * p.dil;
-          ih = bh - rd / p.stride;
-          iw = bw - sd / p.stride;
-          ok = ok && ((oh + p.pad) % p.stride == rd % p.stride) && ((ow + p.pad) % p.stride == sd % p.stride);
-        }
-        ok = ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
-        if (ok) mask |= 1u << (r * p.S + s_);
-      }
-    const int csrc = (lane & 7) ^ ((4 * i + (lane >> 4)) & 7);
-    maskA[i] = mask;
-    baseA[i] = (unsigned)((((n * p.Hin + bh) * p.Win + bw) * p.ldx + csrc * 4) * 4);
-  }
-  unsigned voffB[B_PER];
-#pragma unroll
-  for (int i = 0; i < B_PER; ++i) {
-    const int csrc = (lane & 7) ^ ((4 * i + (lane >> 4)) & 7);
-    voffB[i] = (unsigned)(((size_t)(n0 + wave * (BN / 4) + i * 8 + rsub) * wK + csrc * 4) * 4);
-  }
-  int toffs[RS_T];
-#pragma unroll
-  for (int t = 0; t < RS_T; ++t) {
-    const int r = t / p.S, s_ = t - (t / p.S) * p.S;
-    if (!TR)
-      toffs[t] = (r * p.dil * p.Win + s_ * p.dil) * p.ldx * 4;
-    else
-      toffs[t] = -(((r * p.dil) / p.stride) * p.Win + (s_ * p.dil) / p.stride) * p.ldx * 4;
-  }
-  const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x80000000, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x80000000, 0x00020000);
-
-  auto issue = [&](auto tapc, int c, int slot) {
-    constexpr int t = decltype(tapc)::value;
-    float* As = smem + slot * STAGE;
-    float* Bs = As + BM * BK;
-    const int so_a = c * (BK * 4);
-    const int so_b = (c * RS_T + t) * (BK * 4);
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const unsigned vo = ((maskA[i] >> t) & 1u) ? baseA[i] + (unsigned)toffs[t] : OOB;
-      dma16_to_lds_s(rx_, As + (wave * 32 + i * 8) * BK, vo, so_a);
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) dma16_to_lds_s(rw_, Bs + (wave * (BN / 4) + i * 8) * BK, voffB[i], so_b);
-  };
-
-  f32x16 acc[MREP][NREP];
-#pragma unroll
-  for (int i = 0; i < MREP; ++i)
-#pragma unroll
-    for (int j = 0; j < NREP; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  constexpr bool TWO_LEVEL = CONV_TWO_LEVEL && TL;
-  f32x16 acc2[TWO_LEVEL ? MREP : 1][TWO_LEVEL ? NREP : 1];
-  if constexpr (TWO_LEVEL) {
-#pragma unroll
-    for (int i = 0; i < MREP; ++i)
-#pragma unroll
-      for (int j = 0; j < NREP; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
-  }
-  auto flush = [&] {
-    if constexpr (TWO_LEVEL) {
-#pragma unroll
-      for (int i = 0; i < MREP; ++i)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            acc2[i][j][e] += acc[i][j][e];
-            acc[i][j][e] = 0.f;
-          }
-    }
-  };
-
-  // fragment addressing: tile row (wm*64 + i*32 + l31) or (wn*BN/2 + j*32 + l31); chunk (k8*2 + lhi) ^ ((l31 >> 1) & 7)
-  const int rsw = (l31 >> 1) & 7;
-  int koff[4];
-#pragma unroll
-  for (int k8 = 0; k8 < 4; ++k8) koff[k8] = (((k8 * 2 + lhi) ^ rsw) * 4);
-  const int arow = (wm * 64 + l31) * BK;
-  const int brow = (BM + wn * (BN / 2) + l31) * BK;
-
-  auto compute = [&](int slot) {
-    const float* base = smem + slot * STAGE;
-#pragma unroll
-    for (int k8 = 0; k8 < 4; ++k8) {
-      f32x4 a[MREP], b[NREP];
-#pragma unroll
-      for (int i = 0; i < MREP; ++i) a[i] = *reinterpret_cast<const f32x4*>(base + arow + i * 32 * BK + koff[k8]);
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) b[j] = *reinterpret_cast<const f32x4*>(base + brow + j * 32 * BK + koff[k8]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < MREP; ++i)
-#pragma unroll
-          for (int j = 0; j < NREP; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  const int c_begin = kt0 / RS_T, c_end = KT / RS_T;
-  int slot = 0;
-  auto step = [&](auto tapc, int c) {
-    constexpr int t = decltype(tapc)::value;
-    // this K-step's tile has landed for this wave (only one stage is ever in flight) ...
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ... and for every wave after the barrier, which also says: everybody is done reading the other slot
-    __builtin_amdgcn_s_barrier();
-    if constexpr (t + 1 < RS_T) {
-      issue(std::integral_constant<int, t + 1>{}, c, slot ^ 1);
-    } else {
-      if (c + 1 < c_end) issue(std::integral_constant<int, 0>{}, c + 1, slot ^ 1);
-    }
-    compute(slot);
-    slot ^= 1;
-  };
-  if (c_begin < c_end) issue(std::integral_constant<int, 0>{}, c_begin, 0);
-  for (int c = c_begin; c < c_end; ++c) {
-    step(std::integral_constant<int, 0>{}, c);
-    if constexpr (RS_T == 9) {
-      step(std::integral_constant<int, 1>{}, c);
-      step(std::integral_constant<int, 2>{}, c);
-      step(std::integral_constant<int, 3>{}, c);
-      step(std::integral_constant<int, 4>{}, c);
-      step(std::integral_constant<int, 5>{}, c);
-      step(std::integral_constant<int, 6>{}, c);
-      step(std::integral_constant<int, 7>{}, c);
-      step(std::integral_constant<int, 8>{}, c);
-    }
-    // bound the fp32 MFMA chain to 576 (3x3: two channel blocks x 9 taps) / 512 (1x1) products: the chain's
-    // rounding noise grows ~sqrt(length) while a blocked CPU sum does not (in-situ backward parity)
-    if (((c - c_begin) & (RS_T == 9 ? 1 : 15)) == (RS_T == 9 ? 1 : 15)) flush();
-  }
-  if constexpr (TWO_LEVEL) {
-#pragma unroll
-    for (int i = 0; i < MREP; ++i)
-#pragma unroll
-      for (int j = 0; j < NREP; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
-  }
-  // no DMA is outstanding here (the last step issued none, its wait drained the queue); the ring is reused as the
-  // epilogue's transposition slabs once every wave has left the K loop
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m, nullptr);
 }
 
 // Split-K epilogue: y = sum_ks part[ks] (+bias) (+add); optional fp64 channel statistics.
@@ -1176,11 +830,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
   // XCD-aware order: workgroups that share a pixel range (same ks) and neighbouring taps / tiles read the
   // same x and dy rows; give each XCD a contiguous chunk of the logical order so those rows are fetched
   // into one L2 instead of all eight.
-#if WGRAD_XCD
   int b = xcd_remap(blockIdx.x, gridDim.x);
-#else
-  int b = blockIdx.x;
-#endif
   const int tci = b % p.tiles_ci; b /= p.tiles_ci;
   const int tco = b % p.tiles_co; b /= p.tiles_co;
   const int tap = b % RS;
@@ -1248,17 +898,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
   // WGRAD_ABL (measurement only, results are wrong): 1 = no global loads in the loop, 2 = additionally no
   // LDS stores / barriers per step, 3 = additionally fragments from registers (pure MFMA ceiling)
   if (kbeg < kend) prefetch(kbeg);
-#if WGRAD_ABL >= 2
-#pragma unroll
-  for (int i = 0; i < Y_PER; ++i)
-    *reinterpret_cast<f32x4*>(&Ys[(yr + i * YROWS) * TM + yc * 4]) = ry[i];
-#pragma unroll
-  for (int i = 0; i < X_PER; ++i)
-    *reinterpret_cast<f32x4*>(&Xs[(xr + i * XROWS) * TN + xc * 4]) = rx[i];
-  __syncthreads();
-#endif
   for (int kb = kbeg; kb < kend; kb += 32) {
-#if WGRAD_ABL < 2
 #pragma unroll
     for (int i = 0; i < Y_PER; ++i)
       *reinterpret_cast<f32x4*>(&Ys[(yr + i * YROWS) * TM + yc * 4]) = ry[i];
@@ -1266,7 +906,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
     for (int i = 0; i < X_PER; ++i)
       *reinterpret_cast<f32x4*>(&Xs[(xr + i * XROWS) * TN + xc * 4]) = rx[i];
     __syncthreads();
-#endif
     // fragments of k-pair kp+1 are read from LDS while the MFMAs of k-pair kp issue (the compiler
     // otherwise waits for every ds_read right in front of its 4 MFMAs)
     float fa[2][MREP], fb[2][NREP];
@@ -1277,32 +916,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
       if (kp + 1 < 16) {
-#if WGRAD_ABL >= 3
-#pragma unroll
-        for (int i = 0; i < MREP; ++i) { fa[(kp + 1) & 1][i] = fa[kp & 1][i]; asm volatile("" : "+v"(fa[(kp + 1) & 1][i])); }
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) { fb[(kp + 1) & 1][j] = fb[kp & 1][j]; asm volatile("" : "+v"(fb[(kp + 1) & 1][j])); }
-#else
 #pragma unroll
         for (int i = 0; i < MREP; ++i)
           fa[(kp + 1) & 1][i] = Ys[(2 * (kp + 1) + lhi) * TM + wm * (TM / 2) + i * 32 + l31];
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
           fb[(kp + 1) & 1][j] = Xs[(2 * (kp + 1) + lhi) * TN + wn * (TN / 2) + j * 32 + l31];
-#endif
       }
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
 #pragma unroll
         for (int j = 0; j < NREP; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][i], fb[kp & 1][j], acc[i][j], 0, 0, 0);
-#if WGRAD_ABL == 0
-      if (kp == WGRAD_PF_KP && kb + 32 < kend) prefetch(kb + 32);
-#endif
+      if (kp == 3 && kb + 32 < kend) prefetch(kb + 32);
     }
-#if WGRAD_ABL < 2
     __syncthreads();
-#endif
   }
 
   float* out = p.dw + (size_t)ks * p.Co_pad * RS * p.Ci;
@@ -1361,11 +989,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int RS = p.R * p.S;
-#if WGRAD_XCD
   int b = xcd_remap(blockIdx.x, gridDim.x);
-#else
-  int b = blockIdx.x;
-#endif
   // Order inside a K slice decides which operand block the ~64 workgroups resident on an XCD share through its L2
   // (a workgroup streams one x block [pixels, 128 ci] and one dy block [pixels, 128 co]):
   //   0: ci tile fastest, then co tile, then tap   (64 neighbours: 1 tap, 2 co tiles, 32 ci tiles -> 34 blocks)
@@ -1689,9 +1313,6 @@ int semseg_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_dgrad, 
   return semseg_launch_status();
 }
 
-#ifndef CONV_BM256
-#define CONV_BM256 0
-#endif
 int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* block_starts_dev,
                                    int nconv, int total_blocks, hipStream_t stream) {
   if (!descs_dev || !block_starts_dev || nconv < 1 || total_blocks < 1) return SEMSEG_EINVAL;
@@ -1701,9 +1322,7 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 
 static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratch,
                        size_t scratch_floats, hipStream_t stream) {
-  // 256-row tiles (8 waves) halve the weight-panel traffic per MFMA; used when the grid is large
-  const bool big = CONV_BM256 && BN == 128 && ((a.M + 255) / 256) * ((a.Nout + 127) / 128) >= 512;
-  const int BMr = big ? 256 : 128;
+  constexpr int BMr = 128;
   const int tiles_m = (a.M + BMr - 1) / BMr;
   ConvArgs p = a;
   if (p.batch > 1) { scratch = nullptr; scratch_floats = 0; }   // batched GEMM: the batch fills the chip, no split-K
@@ -1765,12 +1384,9 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   }
   const int grid = p.full_tiles + (tiles - p.full_tiles) * ksplit;
   // buffer-load kernels need 1x1 / 3x3 taps, split points on chunk boundaries and < 2 GB operands
-#ifndef CONV_BUFLOAD
-#define CONV_BUFLOAD 1
-#endif
   const int RSv = a.R * a.S;
   const size_t x_bytes = (size_t)a.N * a.Hin * a.Win * a.ldx * 4, w_bytes = (size_t)p.tiles_n * BN * KT * BK * 4;
-  const bool bl = CONV_BUFLOAD && !big && (RSv == 1 || RSv == 9) && (p.kt_per % RSv == 0) &&
+  const bool bl = (RSv == 1 || RSv == 9) && (p.kt_per % RSv == 0) &&
                   x_bytes < 0x7FFF0000ull && w_bytes < 0x7FFF0000ull;
   // Two-level accumulation whenever the reduction is longer than one flush interval (K > 576).  Round 1 used it for
   // K >= 4096 only; the in-situ backward test of round 2 showed single chains of K = 1152 ... 2304 (aux.0 /
@@ -1789,41 +1405,18 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     if (tl) LAUNCH_CONV_(BM_, BN_, TR_, RS_, true);                            \
     else LAUNCH_CONV_(BM_, BN_, TR_, RS_, false);                              \
   } while (0)
-#ifndef CONV_DMA_DEFAULT
-#define CONV_DMA_DEFAULT 0
-#endif
-  // SEMSEG_CONV_DMA (read per call): 1 = direct-to-LDS kernel for every eligible conv, 2 = only 3x3, 3 = only 1x1
-  const char* cd_s = getenv("SEMSEG_CONV_DMA");
-  const int cd = cd_s ? atoi(cd_s) : CONV_DMA_DEFAULT;
-  const bool dmac = bl && a.bnr_n == 0 && (cd == 1 || (cd == 2 && RSv == 9) || (cd == 3 && RSv == 1));
-#define LAUNCH_DMA_(BN_, TR_, RS_, TL_) \
-  conv_igemm_dma_kernel<BN_, TR_, RS_, TL_><<<dim3(grid, p.batch), 256, 0, stream>>>(p)
-#define LAUNCH_DMA(BN_, TR_, RS_)                                     \
-  do {                                                                \
-    if (tl) LAUNCH_DMA_(BN_, TR_, RS_, true);                         \
-    else LAUNCH_DMA_(BN_, TR_, RS_, false);                           \
-  } while (0)
 #define LAUNCH_RS(BM_, BN_, TR_)                                   \
   do {                                                             \
-    if (dmac && RSv == 9) LAUNCH_DMA(BN_, TR_, 9);                 \
-    else if (dmac) LAUNCH_DMA(BN_, TR_, 1);                        \
-    else if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);        \
+    if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);             \
     else if (bl) LAUNCH_CONV(BM_, BN_, TR_, 1);                    \
     else LAUNCH_CONV(BM_, BN_, TR_, 0);                            \
   } while (0)
-#if CONV_BM256
-  if (big) {
-    if (transposed) LAUNCH_CONV(256, 128, true, 0); else LAUNCH_CONV(256, 128, false, 0);
-  } else
-#endif
   if (BN == 128) {
     if (transposed) LAUNCH_RS(128, 128, true); else LAUNCH_RS(128, 128, false);
   } else {
     if (transposed) LAUNCH_RS(128, 64, true); else LAUNCH_RS(128, 64, false);
   }
 #undef LAUNCH_RS
-#undef LAUNCH_DMA
-#undef LAUNCH_DMA_
 #undef LAUNCH_CONV
 #undef LAUNCH_CONV_
   if (ksplit > 1) {
@@ -1946,7 +1539,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   const int t128 = ((Co + 127) / 128) * (Ci / 128) * RS;
   const bool small_tiles = (RS == 1 && t128 <= 16 && M < 32768) || (RS > 1 && t128 <= 36 && M < 8192);
   const char* small_s = getenv("SEMSEG_WGRAD_SMALL");   // "0": never fall back to 64 x 64 tiles (tests / tuning)
-  const bool allow_small = WGRAD_SMALL_TILES && !(small_s && small_s[0] == '0');
+  const bool allow_small = !(small_s && small_s[0] == '0');
   const bool big = (Ci % 128 == 0) && (Co >= 128) && !(allow_small && small_tiles);
   const int TM = big ? 128 : 64, TN = big ? 128 : 64;
   WgradArgs a;
@@ -2021,10 +1614,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   a.ksplit = ksplit;
   a.dw_bs = (long long)(slab * ksplit);
   const dim3 grid(tiles * ksplit, batch);
-#ifndef CONV_WGRAD_LINEAR
-#define CONV_WGRAD_LINEAR 1
-#endif
-  const bool same = CONV_WGRAD_LINEAR && stride == 1 && Ho == H && Wo == W;
+  const bool same = stride == 1 && Ho == H && Wo == W;
   const int mode = !same ? 0 : (RS == 1 && pad == 0) ? 1 : 2;
 #define LAUNCH_WGRAD(TM_, TN_)                                                        \
   do {                                                                                \

@@ -127,13 +127,9 @@ def test_wgrad_128_tile_variants(case, variant, report, monkeypatch):
     assert e < 2e-5
 
 
-@pytest.mark.parametrize("conv_dma", [0, 1])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(case, conv_dma, report, monkeypatch):
-    """conv_dma = 1: the direct-to-LDS forward / data-gradient kernel (SEMSEG_CONV_DMA) instead of the
-    register-staged one, same cases and bounds."""
+def test_conv_fwd_dgrad_wgrad(case, report):
     from semseg_amd import ops
-    monkeypatch.setenv("SEMSEG_CONV_DMA", str(conv_dma))
     N, H, W, Ci, Co, k, s, p, d = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = torch.randn(N, Ci, H, W, generator=g)
