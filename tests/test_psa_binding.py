@@ -2,14 +2,18 @@
 
 `lib/psa/src/__init__.py` builds the pybind module `psamask_gpu` with torch.utils.cpp_extension; it exports
 psamask_forward / psamask_backward with the reference's signature (lib/psa/src/gpu/operator.h:3-4) on top of the C ABI
-of libsemseg_hip.so.  CPU part: the module builds, loads and has that signature, and — where /root/reference is present
-(this container) — the reference's UNMODIFIED lib/psa/functions/psamask.py binds to it (the call reaches the
-front-end's own device check instead of dying on a pybind signature mismatch).  GPU part: golden vectors bit-exactly
-through that module, on a non-default stream too.
+of libsemseg_hip.so.  CPU part: the module builds, loads and has that signature, and the reference's UNMODIFIED
+lib/psa/functions/psamask.py binds to it (the call reaches the front-end's own device check instead of dying on a
+pybind signature mismatch).  GPU part: golden vectors bit-exactly through that module, on a non-default stream too, and
+through the reference's unmodified Python front-end on top of it.
+
+The reference's front-end (functional.py, functions/__init__.py, functions/psamask.py) travels to the GPU box as the
+byte-exact, sha256-checked fixture tests/golden/ref_psa_frontend.npz (tests/golden/make_golden_refpsa.py); where
+/root/reference exists the fixture is also compared with the files there.
 """
+import hashlib
 import importlib
 import os
-import shutil
 import sys
 
 import numpy as np
@@ -17,8 +21,14 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_FN = "/root/reference/lib/psa/functions/psamask.py"
+REF_DIR = "/root/reference/lib/psa"
 GOLD = os.path.join(ROOT, "tests", "golden", "psamask_ref.npz")
+FRONTEND = os.path.join(ROOT, "tests", "golden", "ref_psa_frontend.npz")
+FRONTEND_SHA256 = {   # printed by tests/golden/make_golden_refpsa.py
+    "functional": ("functional.py", "0ab753f2741e0eedcad9bca3449fd4475a46d91f3941eaa2736ff6660efa8a86"),
+    "functions_init": ("functions/__init__.py", "a04f0f6335f78b8181c1754d0ef8c59f3b750d2f378923d0dc68a5fafe5ba2a4"),
+    "functions_psamask": ("functions/psamask.py", "94ef86dc71875eda0cf3ac70fc6d2851052c3e8765e0feb96ac08d46a8445717"),
+}
 
 
 def _module():
@@ -43,14 +53,18 @@ def test_psamask_gpu_module_builds_and_has_the_reference_signature():
 
 
 def _reference_package(tmp_path):
-    """A package `refpsa` = the reference's own lib/psa Python files (copied at test time, never committed) with its
-    `src` sub-package replaced by this repo's lib/psa/src."""
+    """A package `refpsa` = the reference's own lib/psa Python files (unpacked from the sha256-checked fixture at test
+    time) with its `src` sub-package replaced by this repo's lib/psa/src."""
+    fx = np.load(FRONTEND)
     pkg = tmp_path / "refpsa"
     (pkg / "functions").mkdir(parents=True)
     (pkg / "__init__.py").write_text("")
-    shutil.copy("/root/reference/lib/psa/functional.py", pkg / "functional.py")
-    shutil.copy("/root/reference/lib/psa/functions/__init__.py", pkg / "functions" / "__init__.py")
-    shutil.copy(REF_FN, pkg / "functions" / "psamask.py")
+    for key, (rel, digest) in FRONTEND_SHA256.items():
+        raw = fx[key].tobytes()
+        assert hashlib.sha256(raw).hexdigest() == digest, "fixture %s does not have the recorded digest" % key
+        if os.path.isdir(REF_DIR):   # build container: the fixture IS the reference's file
+            assert raw == open(os.path.join(REF_DIR, rel), "rb").read(), rel
+        (pkg / rel).write_bytes(raw)
     os.symlink(os.path.join(ROOT, "lib", "psa", "src"), pkg / "src")
     sys.path.insert(0, str(tmp_path))
     for k in [k for k in sys.modules if k == "refpsa" or k.startswith("refpsa.")]:
@@ -61,10 +75,8 @@ def _reference_package(tmp_path):
         sys.path.remove(str(tmp_path))
 
 
-@pytest.mark.skipif(not os.path.exists(REF_FN), reason="needs /root/reference (build container only)")
 def test_unmodified_reference_function_binds_to_psamask_gpu(tmp_path, monkeypatch):
     PF = _reference_package(tmp_path)
-    assert open(PF.__file__.replace("functional.py", "functions/psamask.py")).read() == open(REF_FN).read()
     # no GPU here: make the reference take its `is_cuda` branch with host tensors
     monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
     monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
@@ -106,7 +118,6 @@ def test_psamask_gpu_module_golden_vectors(report):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(REF_FN), reason="needs /root/reference next to a GPU")
 def test_unmodified_reference_function_on_gpu(tmp_path, report):
     PF = _reference_package(tmp_path)
     fx = np.load(GOLD)
