@@ -2,10 +2,17 @@
 
 `make_dataset` parses the list file exactly as util/dataset.py:17-49 does.  `SemData` decodes on the CPU worker and
 stops there: it returns the decoded uint8 arrays (image RGB [H,W,3], label [H,W]) instead of running cv2 transforms
-on float32 copies (dataset.py:56-70).  `DeviceCollate(compose)` is the DataLoader `collate_fn` that finishes the
-job in the training process: the whole batch goes through semseg_amd.transform.Compose.batch on the GPU and comes
-out as the [B,3,h,w] float / [B,h,w] int64 CUDA tensors the train step consumes (no pinned-memory float batch, no
-per-sample ToTensor/Normalize on the host).
+on float32 copies (dataset.py:56-70).
+
+Who runs what (the DataLoader calls `collate_fn` INSIDE its worker processes when num_workers > 0, and a forked worker
+must never touch HIP):
+  * workers (tool/train.py:202-207 runs 16 of them): file decode only; `raw_collate` passes the list of uint8 pairs
+    through untouched;
+  * training process: `DeviceLoader(loader, compose)` wraps the DataLoader; every raw batch it yields goes through
+    semseg_amd.transform.Compose.batch on the GPU and comes out as the [B,3,h,w] float / [B,h,w] int64 CUDA tensors the
+    train step consumes (no pinned-memory float batch, no per-sample ToTensor/Normalize on the host).
+`DeviceCollate(compose)` is the num_workers == 0 shortcut (collate_fn in the training process); it raises inside a
+worker, and so does a `SemData(transform=...)` whose transform would run there.
 
 Decode: OpenCV is not installed in this image, so files are decoded with PIL.  For lossless files (PNG/BMP/PPM/PGM)
 RGB and 8-bit grey decode to the same bytes `cv2.imread(IMREAD_COLOR)` + BGR2RGB / `IMREAD_GRAYSCALE` produce; JPEG
@@ -16,7 +23,11 @@ rather than converted with a different formula than cv2's.
 import os
 
 import numpy as np
-from torch.utils.data import Dataset
+from torch.utils.data import Dataset, get_worker_info
+
+_WORKER_MSG = ("%s would run the HIP transform chain inside a DataLoader worker process (num_workers > 0): a forked "
+               "worker cannot initialise the GPU.  Keep the workers decode-only: DataLoader(SemData(...), "
+               "collate_fn=raw_collate, num_workers=N) wrapped in DeviceLoader(loader, compose)\n")
 
 def make_dataset(split='train', data_root=None, data_list=None):
     """util/dataset.py:17-49: 'image label' pairs per line (one path per line for split == 'test')."""
@@ -76,19 +87,30 @@ class SemData(Dataset):
         if image.shape[0] != label.shape[0] or image.shape[1] != label.shape[1]:
             raise RuntimeError("image and label sizes differ: %s %s\n" % (image_path, label_path))
         if self.transform is not None:
+            if get_worker_info() is not None:
+                raise RuntimeError(_WORKER_MSG % "SemData(transform=...)")
             image, label = self.transform(image, label)
         return image, label
 
 
+def raw_collate(samples):
+    """collate_fn for decode-only workers: the list of (uint8 image, uint8 label) pairs, untouched (images of one batch
+    have different sizes before the chain's Crop, so there is nothing to stack yet)."""
+    return [(s[0], s[1]) for s in samples]
+
+
 class DeviceCollate(object):
-    """collate_fn: list of (uint8 image, uint8 label) -> (input [B,3,h,w] float32, target [B,h,w] int64) on the GPU,
-    through tool/train.py:194-201's chain built from semseg_amd.transform classes."""
+    """collate_fn for num_workers == 0 only: list of (uint8 image, uint8 label) -> (input [B,3,h,w] float32, target
+    [B,h,w] int64) on the GPU, through tool/train.py:194-201's chain built from semseg_amd.transform classes.  With
+    worker processes use raw_collate + DeviceLoader instead (this raises inside a worker)."""
 
     def __init__(self, compose, device=None):
         self.compose = compose
         self.device = device
 
     def __call__(self, samples):
+        if get_worker_info() is not None:
+            raise RuntimeError(_WORKER_MSG % "DeviceCollate")
         images = [s[0] for s in samples]
         labels = [s[1] for s in samples]
         x, y = self.compose.batch(images, labels, stack=True, device=self.device)
@@ -96,3 +118,26 @@ class DeviceCollate(object):
             raise RuntimeError("DeviceCollate: the chain must end in ToTensor() and give every sample the same size "
                                "(a Crop), as tool/train.py:194-201 does; got per-sample outputs\n")
         return x, y
+
+
+class DeviceLoader(object):
+    """Iterable over a DataLoader whose workers only decode (collate_fn=raw_collate): the device-side chain runs HERE,
+    in the training process, when a batch is taken.  Keeps the loader surface tool/train.py uses: `len(loader)`
+    (train.py:252,297), iteration (train.py:264), `.sampler` / `.dataset` / `.batch_size`."""
+
+    def __init__(self, loader, compose, device=None):
+        if getattr(loader, "collate_fn", None) is not raw_collate:
+            raise RuntimeError("DeviceLoader: build the DataLoader with collate_fn=semseg_amd.dataset.raw_collate "
+                               "(workers decode, the transform chain runs in the training process)\n")
+        self.loader = loader
+        self.collate = DeviceCollate(compose, device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for raw in self.loader:
+            yield self.collate(raw)
+
+    def __getattr__(self, name):
+        return getattr(self.loader, name)

@@ -59,6 +59,81 @@ def test_make_dataset_and_decode(tmp_path):
         ds[0]
 
 
+class _HostChain(object):
+    """Stand-in for transform.Compose on a box without a GPU: same `batch` call shape, centre-crops on the host."""
+
+    def __init__(self, size):
+        self.size = size
+        self.pids = []
+
+    def batch(self, images, labels, stack=True, device=None):
+        import torch
+        self.pids.append(os.getpid())
+        s = self.size
+        x = torch.stack([torch.from_numpy(np.ascontiguousarray(im[:s, :s].transpose(2, 0, 1))).float() for im in images])
+        y = torch.stack([torch.from_numpy(np.ascontiguousarray(lb[:s, :s])).long() for lb in labels])
+        return x, y
+
+
+def test_workers_decode_only_and_chain_runs_in_training_process(tmp_path):
+    """num_workers = 2: the workers return raw uint8 pairs, the chain runs in THIS process when the batch is taken;
+    DeviceCollate / SemData(transform=) refuse to run inside a worker (util/dataset.py:61-71 decodes in 16 workers)."""
+    import torch
+    from semseg_amd import dataset as D
+    tmp = str(tmp_path)
+    samples = _write_set(tmp, n=6)
+    ds = D.SemData("train", tmp, os.path.join(tmp, "train.txt"))
+    chain = _HostChain(40)
+    inner = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, num_workers=2, collate_fn=D.raw_collate)
+    loader = D.DeviceLoader(inner, chain)
+    assert len(loader) == 2 and loader.batch_size == 3 and loader.dataset is ds
+    seen = 0
+    for x, y in loader:
+        assert tuple(x.shape) == (3, 3, 40, 40) and y.dtype == torch.int64
+        for j in range(3):
+            img, lab = samples[seen + j]
+            assert np.array_equal(x[j].numpy(), img[:40, :40].transpose(2, 0, 1).astype(np.float32))
+            assert np.array_equal(y[j].numpy(), lab[:40, :40].astype(np.int64))
+        seen += 3
+    assert seen == 6 and set(chain.pids) == {os.getpid()}
+    # the old recipe (chain as the workers' collate_fn) fails loudly instead of initialising HIP in a forked child
+    bad = torch.utils.data.DataLoader(ds, batch_size=3, num_workers=2, collate_fn=D.DeviceCollate(chain))
+    with pytest.raises(RuntimeError, match="worker"):
+        next(iter(bad))
+    ds_t = D.SemData("val", tmp, os.path.join(tmp, "train.txt"), transform=lambda a, b: (a, b))
+    bad2 = torch.utils.data.DataLoader(ds_t, batch_size=1, num_workers=1, collate_fn=D.raw_collate)
+    with pytest.raises(RuntimeError, match="worker"):
+        next(iter(bad2))
+    with pytest.raises(RuntimeError, match="raw_collate"):
+        D.DeviceLoader(torch.utils.data.DataLoader(ds, batch_size=3), chain)
+
+
+@pytest.mark.gpu
+def test_device_loader_with_worker_processes(tmp_path):
+    """The documented recipe on the GPU: 2 decode workers + the device chain in the
+    training process, bit-exact against the oracle."""
+    import torch
+    from semseg_amd import dataset as D, transform as T
+    from oracle import transform as otf
+    tmp = str(tmp_path)
+    samples = _write_set(tmp, n=8)
+    ops = tc.train_chain((49, 49))
+    torch.zeros(1, device="cuda")       # HIP is initialised in the parent BEFORE the workers fork
+    ds = D.SemData("train", tmp, os.path.join(tmp, "train.txt"))
+    inner = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=2, collate_fn=D.raw_collate)
+    loader = D.DeviceLoader(inner, tc.build_chain(T, ops))
+    random.seed(5)
+    got = [(x, y) for x, y in loader]
+    assert len(got) == 2
+    random.seed(5)
+    for b, (x, y) in enumerate(got):
+        assert x.is_cuda and tuple(x.shape) == (4, 3, 49, 49) and y.dtype == torch.int64
+        for i in range(4):
+            img, lab = samples[4 * b + i]
+            oi, ol = otf.run(ops, np.float32(img), lab.copy())
+            assert np.array_equal(x[i].cpu().numpy(), oi.numpy()) and np.array_equal(y[i].cpu().numpy(), ol.numpy())
+
+
 @pytest.mark.gpu
 def test_loader_with_device_collate(tmp_path):
     import torch

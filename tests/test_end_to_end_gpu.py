@@ -1,5 +1,5 @@
 """The pieces either side of the train step composed the way tool/train.py:194-304 composes them: list file ->
-SemData (decode) -> DataLoader with the device-side transform chain as collate_fn -> fused train step (forward, two
+SemData (decode in 2 worker processes) -> DeviceLoader (device-side transform chain in the training process) -> fused train step (forward, two
 cross-entropy losses, backward, SGD with poly LR) -> intersectionAndUnionGPU on the returned prediction -> state-dict
 save / load.  Checks plumbing (shapes, dtypes, devices), that the loss goes down on a learnable toy set, and that a
 reloaded checkpoint predicts identically."""
@@ -48,8 +48,10 @@ def test_train_loop_end_to_end(tmp_path):
     classes, crop, bs = 4, 65, 4
     _toy_set(tmp, 8, classes)
     chain = tc.build_chain(T, tc.train_chain((crop, crop), scale=(0.8, 1.25), rotate=(-10, 10)))
-    loader = torch.utils.data.DataLoader(D.SemData("train", tmp, os.path.join(tmp, "train.txt")), batch_size=bs,
-                                         shuffle=True, num_workers=0, drop_last=True, collate_fn=D.DeviceCollate(chain))
+    torch.zeros(1, device="cuda")
+    loader = D.DeviceLoader(torch.utils.data.DataLoader(D.SemData("train", tmp, os.path.join(tmp, "train.txt")),
+                                                        batch_size=bs, shuffle=True, num_workers=2, drop_last=True,
+                                                        collate_fn=D.raw_collate), chain)
     torch.manual_seed(0)
     random.seed(0)
     model = PSPNet(layers=50, classes=classes, zoom_factor=8, dropout=0.1, pretrained=False).cuda().train()
