@@ -137,13 +137,83 @@ def cpu_baseline(layers, classes, size, iters=2, arch="psp"):
 
 
 def _tile_summary():
-    """forward / data-gradient launches per tile width chosen by semseg_amd.ops (first warm-up step)"""
+    """The committed per-shape tile-width table every process runs with (semseg_amd/tile_table.json)."""
+    import hashlib
     from semseg_amd import ops
-    out = {}
-    for key, t in ops.TILE_CHOICE.items():
-        k = "%s_128x%d" % (key[0], t)
-        out[k] = out.get(k, 0) + 1
-    return out
+    if not os.path.exists(ops.TILE_TABLE_PATH):
+        return "none (static default: 128-wide tiles)"
+    return "semseg_amd/tile_table.json: %d shapes, sha256 %s" % (
+        len(ops.TILE_CHOICE), hashlib.sha256(open(ops.TILE_TABLE_PATH, "rb").read()).hexdigest()[:12])
+
+
+def module_path_step_time(args, dev, world, rank, B, steps, warmup):
+    """The reference's own loop body (tool/train.py:269-276, 299-304) on the drop-in nn.Module API: torch.optim.SGD
+    over the eight parameter groups of train.py:125-140, nn.SyncBatchNorm conversion + DistributedDataParallel under
+    torch.distributed (train.py:142,157), autograd driving the HIP engine through semseg_amd.module_base._NetFunction.
+    Returns seconds per step (max over ranks)."""
+    import torch.nn as nn
+    from semseg_amd.trainer import poly_learning_rate
+    torch.manual_seed(0)
+    if args.arch == "psp":
+        from model.pspnet import PSPNet
+        model = PSPNet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
+        modules_new = [model.ppm, model.cls, model.aux]
+    else:
+        from model.psanet import PSANet
+        model = PSANet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
+        modules_new = [model.psa, model.cls, model.aux]
+    modules_ori = [model.layer0, model.layer1, model.layer2, model.layer3, model.layer4]
+    base_lr, index_split = 0.01, 5
+    params_list = [dict(params=m.parameters(), lr=base_lr) for m in modules_ori]
+    params_list += [dict(params=m.parameters(), lr=base_lr * 10) for m in modules_new]
+    optimizer = torch.optim.SGD(params_list, lr=base_lr, momentum=0.9, weight_decay=1e-4)
+    distributed = dist.is_initialized()
+    if distributed:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        model = torch.nn.parallel.DistributedDataParallel(model.to(dev), device_ids=[dev.index])
+    else:
+        model = model.to(dev)
+    model.train()
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(B, 3, args.size, args.size, generator=g).to(dev)
+    y = torch.randint(0, args.classes, (B, args.size, args.size), generator=g).to(dev)
+    max_iter = steps + warmup + 1
+
+    def one(it):
+        output, main_loss, aux_loss = model(x, y)
+        loss = main_loss + 0.4 * aux_loss
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        lr = poly_learning_rate(base_lr, it, max_iter)
+        for index in range(0, index_split):
+            optimizer.param_groups[index]['lr'] = lr
+        for index in range(index_split, len(optimizer.param_groups)):
+            optimizer.param_groups[index]['lr'] = lr * 10
+        return main_loss
+
+    for it in range(warmup):
+        one(it)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for it in range(warmup, warmup + steps):
+        ml = one(it)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if distributed:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(ml.item())
+    del model, optimizer
+    torch.cuda.empty_cache()
+    return dt / steps, loss_val
 
 
 def main():
@@ -158,6 +228,10 @@ def main():
     ap.add_argument("--arch", default="psp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--path", default="trainer", choices=["trainer", "module"],
+                    help="trainer: the fused loop body (semseg_amd.Trainer) is the timed value and the drop-in nn.Module "
+                         "+ torch.optim.SGD loop is timed beside it (module_path); module: the other way round")
+    ap.add_argument("--module-steps", type=int, default=6, help="timed steps of the path reported beside the value")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,9 +267,12 @@ def main():
     x = torch.randn(B, 3, args.size, args.size, generator=g).to(dev)
     y = torch.randint(0, args.classes, (B, args.size, args.size), generator=g).to(dev)
 
-    max_iter = args.steps + args.warmup + 1 + ISO_STEPS
+    primary_trainer = args.path == "trainer"
+    steps_t = args.steps if primary_trainer else args.module_steps
+    warm_t = args.warmup if primary_trainer else 2
+    max_iter = steps_t + warm_t + 1 + ISO_STEPS
     it = 0
-    for _ in range(args.warmup):
+    for _ in range(warm_t):
         tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
         it += 1
     kt = None
@@ -208,7 +285,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(args.steps):
+    for _ in range(steps_t):
         _, main_loss, aux_loss = tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
         it += 1
     torch.cuda.synchronize()
@@ -221,6 +298,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(main_loss.item())
+    sec_trainer = dt / steps_t
 
     # Serialized leg (every rank runs it: the steps contain the SyncBN / gradient collectives): ISO_STEPS more steps
     # with all kernels on one stream, HIP-event timed on rank 0 -> per-kernel rates that are not inflated by the
@@ -236,6 +314,31 @@ def main():
         torch.cuda.synchronize()
         for e, sw, hp in saved:
             e.side_wgrad, e.hipri_main, e.ktimer = sw, hp, None
+    kfam = kt_iso.summary() if kt_iso is not None else None
+    kfam_in = kt.summary() if kt is not None else None
+    roof = None
+    if kt is not None:
+        roof = kt_iso.roofline(PEAK_F32_MFMA_TFLOPS)
+        ins = kt.roofline(PEAK_F32_MFMA_TFLOPS, family=roof["kernel"])
+        roof["in_step"] = {k: ins[k] for k in ("achieved", "frac", "avg_launch_us", "launches")}
+
+    # The other path: the reference's unchanged loop body on the nn.Module API (torch.optim.SGD, autograd, DDP).
+    # The Trainer's engine (activation arena, flat buffers) is released first.
+    n_sync = None
+    for e in tr.engines.values():
+        n_sync = getattr(e, "syncbn_collectives_per_step", None)
+    del tr, model, kt, kt_iso
+    torch.cuda.empty_cache()
+    loss_trainer = loss_val
+    sec_module = loss_module = None
+    if args.module_steps > 0 or not primary_trainer:
+        sec_module, loss_module = module_path_step_time(args, dev, world, rank, B,
+                                                        args.module_steps if primary_trainer else args.steps,
+                                                        2 if primary_trainer else args.warmup)
+    if primary_trainer:
+        dt = sec_trainer * args.steps
+    else:
+        dt, loss_val = sec_module * args.steps, loss_module
 
     if rank == 0:
         ips = args.global_batch * args.steps / dt
@@ -252,22 +355,31 @@ def main():
                                    % ("P" if args.arch == "psp" else "A", args.layers, args.size, args.size,
                                       args.classes, args.global_batch, B),
                        "parallelism": "dp%d" % world,
-                       "tile_widths_measured_in_warmup": _tile_summary()},
+                       "path": ("semseg_amd.Trainer (fused loop body of tool/train.py:269-276)" if primary_trainer else
+                                "nn.Module drop-in + torch.optim.SGD (tool/train.py:269-276 unchanged)"),
+                       "tile_table": _tile_summary()},
             "final_main_loss": round(loss_val, 5),
             "algorithmic_tflop_per_step": round(step_flops / 1e12, 3),
             "whole_step_frac_of_f32_mfma_peak": round(step_flops / (dt / args.steps) / 1e12 / world /
                                                       PEAK_F32_MFMA_TFLOPS, 4),
         }
-        if kt is not None:
+        other = sec_module if primary_trainer else sec_trainer
+        if other is not None:
+            out["module_path" if primary_trainer else "trainer_path"] = {
+                "what": ("tool/train.py:269-276 loop body on the nn.Module API: torch.optim.SGD (8 param groups), "
+                         "autograd, SyncBN convert + DDP under torch.distributed" if primary_trainer
+                         else "semseg_amd.Trainer fused step"),
+                "ms_per_step": round(other * 1e3, 3), "images_per_sec": round(args.global_batch / other, 3),
+                "steps": args.module_steps, "final_main_loss": round(loss_module if primary_trainer else loss_trainer, 5)}
+        if n_sync is not None:
+            out["syncbn_collectives_per_step"] = n_sync
+        if roof is not None:
             # roofline of the dominant kernel family = the serialized leg above (the kernel has the chip to itself);
             # what the same family shows inside the timed region, where it shares the chip, is reported next to it
-            roof = kt_iso.roofline(PEAK_F32_MFMA_TFLOPS)
             roof["measured"] = ("HIP events on the launch stream over %d steps run right after the timed region with "
                                 "every kernel on ONE stream; in the timed region the weight gradients run on a side "
                                 "stream concurrently with the data-gradient / BatchNorm chain, so a launch's duration "
                                 "there includes sharing the chip (in_step)" % ISO_STEPS)
-            ins = kt.roofline(PEAK_F32_MFMA_TFLOPS, family=roof["kernel"])
-            roof["in_step"] = {k: ins[k] for k in ("achieved", "frac", "avg_launch_us", "launches")}
             # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3
             # cannot run inside this process; the file records the exact commands and corrections)
             try:
@@ -282,8 +394,8 @@ def main():
             except Exception:
                 pass
             out["roofline"] = roof
-            out["kernel_families"] = kt_iso.summary()
-            out["kernel_families_in_step"] = kt.summary()
+            out["kernel_families"] = kfam
+            out["kernel_families_in_step"] = kfam_in
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.layers, args.classes, args.size, arch=args.arch)
         print(json.dumps(out))

@@ -65,41 +65,67 @@ class PackedConv:
 NSLOT = 8  # replicas of every fp64 statistics vector (see include/semseg_hip.h)
 
 # ---------------------------------------------------------------------------------------------
-# Tile-width choice for the forward / data-gradient kernel, measured per shape.
+# Tile width of the forward / data-gradient kernel: a COMMITTED per-shape table.
 # Layers with >= 128 output columns can run 128 x 128 or 128 x 64 tiles on the same packed panels.  Which one wins is
 # decided by residency-round quantisation and K-split overhead, not by the tile's own efficiency: at bs 16 the 900-tile
-# layer3 launches (1.76 rounds of 512 resident 128 x 128 workgroups) are 5-10 % faster with 128 x 64 tiles while
-# layer4 / cls.0 are not; at per-GPU batch 2-8 nearly every layer prefers the narrow tile to a 2-4 way K split
-# (DESIGN.md section 8.2 item 8).  No static rule covered batch 2 / 4 / 8 / 16 and 473 / 713 inputs, so the first
-# call of each (direction, shape) times both widths on the real operands (plain epilogue, scratch output, device idle)
-# and keeps 64 only when it wins by >= 3 %.  SEMSEG_TILE_TUNE=0 disables it (always 128); TILE_CHOICE is the table.
+# layer3 launches are 5-10 % faster with 128 x 64 tiles while layer4 / cls.0 are not; at per-GPU batch 2-8 nearly every
+# layer prefers the narrow tile to a 2-4 way K split.  No static rule covered batch
+# 2 / 4 / 8 / 16 and 473 / 713 inputs, so the choice is MEASURED per shape — but offline: scripts/make_tile_table.py
+# times both widths on the GPU for the BASELINE.json configurations and writes semseg_amd/tile_table.json, which is
+# committed.  Every process (bench, profiles, tests, every rank of a job) therefore runs the same kernels and the same
+# K splits (round 2 timed inside the first step: two runs could settle on different widths for a near-tie shape).
+# A shape that is not in the table runs the static default (128 wide when the layer has >= 128 output columns).
+# SEMSEG_TILE_TUNE=1 (used by that script only) times unknown shapes on first use and adds them to TILE_CHOICE.
 # ---------------------------------------------------------------------------------------------
+import json as _json
 import os as _os
 
-TILE_TUNE = _os.environ.get("SEMSEG_TILE_TUNE", "1") != "0"
-TILE_CHOICE = {}
+TILE_TABLE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tile_table.json")
+TILE_TUNE = _os.environ.get("SEMSEG_TILE_TUNE", "0") == "1"
 
 
-def _tuned_tile(key, out_floats, launch):
-    """launch(tile, out_tensor) -> return code of a side-effect-free launch of this shape."""
+def tile_key(kind, N, H, W, Ci, Co, R, S, stride, pad, dil):
+    """kind "fwd" | "dgrad"; N, H, W = batch and INPUT size of the convolution (both directions)."""
+    return "%s|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d" % (kind, N, H, W, Ci, Co, R, S, stride, pad, dil)
+
+
+def load_tile_table(path=TILE_TABLE_PATH):
+    if not _os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return {k: int(v) for k, v in _json.load(f)["tiles"].items()}
+
+
+TILE_CHOICE = load_tile_table()
+
+
+def _tuned_tile(key, dflt, device, out_floats, launch):
+    """Table lookup; with SEMSEG_TILE_TUNE=1 an unknown shape is timed once (launch(tile, out_tensor) -> return code of a
+    side-effect-free launch of this shape into a scratch output on the operands' device)."""
     t = TILE_CHOICE.get(key)
     if t is not None:
         return t
-    tmp = torch.empty(out_floats, dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
+    if not TILE_TUNE:
+        return dflt
+    tmp = torch.empty(out_floats, dtype=torch.float32, device=device)
+    torch.cuda.synchronize(device)
     best = {}
-    for tile in (128, 64, 128, 64):
+    for tile in (128, 64, 128, 64, 128, 64):
         _ck(launch(tile, tmp), "tile tuning")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(2):
+        for _ in range(3):
             _ck(launch(tile, tmp), "tile tuning")
         e1.record()
         e1.synchronize()
         best[tile] = min(best.get(tile, 1e30), e0.elapsed_time(e1))
     t = 64 if best[64] < 0.97 * best[128] else 128
     TILE_CHOICE[key] = t
+    TILE_TIMES[key] = (round(best[128] / 3, 4), round(best[64] / 3, 4))
     return t
+
+
+TILE_TIMES = {}   # key -> (ms with 128-wide tiles, ms with 64-wide tiles), filled in tuning mode only
 
 
 def _scr(scratch):
@@ -116,10 +142,12 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
     tile = pk.tile_fwd
-    if tile == 128 and TILE_TUNE:
-        tile = _tuned_tile(("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil, ldx, ldy), N * Ho * Wo * ldy,
+    if tile == 128:
+        ldt = roundup(pk.Co, 4)
+        tile = _tuned_tile(tile_key("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), 128, x.device,
+                           N * Ho * Wo * ldt,
                            lambda t, out: lib.semseg_conv_fwd(
-                               _p(x), ldx, _p(pk.w_fwd), _p(out), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
+                               _p(x), ldx, _p(pk.w_fwd), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
                                pad, dil, None, None, 0, None, 0, None, 1, t, *_scr(scratch), _stream()))
     _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
                             pk.R, pk.S, stride, pad, dil, _p(bias), _p(scale), int(relu), _p(add), ldadd,
@@ -130,15 +158,19 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
 def chosen_tile(kind, pk, N, H, W, stride, pad, dil, ld_in, ld_out):
     """Tile width the (already measured) shape runs with; kind "fwd" | "dgrad".  For kernel-family labels."""
     dflt = pk.tile_fwd if kind == "fwd" else pk.tile_dgrad
-    return TILE_CHOICE.get((kind, N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil, ld_in, ld_out), dflt)
+    if dflt != 128:
+        return dflt
+    return TILE_CHOICE.get(tile_key(kind, N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), dflt)
 
 
 def _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch):
     tile = pk.tile_dgrad
-    if tile == 128 and TILE_TUNE:
-        tile = _tuned_tile(("dgrad", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil, lddy, lddx), N * H * W * lddx,
+    if tile == 128:
+        ldt = roundup(pk.Ci, 4)
+        tile = _tuned_tile(tile_key("dgrad", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), 128, dy.device,
+                           N * H * W * ldt,
                            lambda t, out: lib.semseg_conv_dgrad(
-                               _p(dy), lddy, _p(pk.w_dgrad), _p(out), lddx, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S,
+                               _p(dy), lddy, _p(pk.w_dgrad), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S,
                                stride, pad, dil, None, 0, t, *_scr(scratch), _stream()))
     return tile
 
