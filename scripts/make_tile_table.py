@@ -1,0 +1,52 @@
+"""Regenerate semseg_amd/tile_table.json on an MI355X: for every forward / data-gradient shape of the BASELINE.json
+configurations (PSPNet-101 473^2 at per-GPU batch 16 / 8 / 4 / 2, PSANet-101 465^2 at 16 / 2, PSPNet-101 713^2 at 2)
+time 128 x 128 against 128 x 64 tiles on real operands (semseg_amd.ops._tuned_tile, 3 interleaved rounds of 3 launches,
+device idle) and keep 64 where it wins by >= 3 %.  The table is committed; nothing times tiles at run time.
+
+    SEMSEG_TILE_TUNE=1 python scripts/make_tile_table.py [out.json]        (GPU box; copy the result into semseg_amd/)
+"""
+import json
+import os
+import sys
+
+os.environ["SEMSEG_TILE_TUNE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from semseg_amd import ops  # noqa: E402
+from semseg_amd.trainer import Trainer  # noqa: E402
+
+CONFIGS = [("psp", 101, 473, 150, b) for b in (16, 8, 4, 2)] + [("psa", 101, 465, 150, b) for b in (16, 2)] + \
+          [("psp", 101, 713, 19, 2)]
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "tile_table.json")
+    ops.TILE_CHOICE.clear()      # measure everything afresh
+    for arch, layers, size, classes, bs in CONFIGS:
+        torch.manual_seed(0)
+        if arch == "psp":
+            from model.pspnet import PSPNet
+            m = PSPNet(layers=layers, classes=classes, zoom_factor=8, pretrained=False)
+        else:
+            from model.psanet import PSANet
+            m = PSANet(layers=layers, classes=classes, zoom_factor=8, pretrained=False)
+        m = m.cuda().train()
+        tr = Trainer(m, sync_bn=False)
+        x = torch.randn(bs, 3, size, size, device="cuda")
+        y = torch.randint(0, classes, (bs, size, size), device="cuda")
+        n0 = len(ops.TILE_CHOICE)
+        tr.step(x, y)
+        torch.cuda.synchronize()
+        print("%s%d %d^2 bs %d: %d new shapes" % (arch, layers, size, bs, len(ops.TILE_CHOICE) - n0), flush=True)
+        del tr, m, x, y
+        torch.cuda.empty_cache()
+    tiles = dict(sorted(ops.TILE_CHOICE.items()))
+    doc = {"generated_by": "scripts/make_tile_table.py (3 x 3 launches per width, 64 kept when >= 3 % faster)",
+           "configs": ["%s%d_%d_c%d_bs%d" % c for c in CONFIGS],
+           "tiles": tiles,
+           "ms_128_vs_64": {k: list(v) for k, v in sorted(ops.TILE_TIMES.items())}}
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "w") as f:
+        json.dump(doc, f, indent=0, sort_keys=False)
+    n64 = sum(1 for v in tiles.values() if v == 64)
+    print("wrote %s: %d shapes, %d run 128 x 64 tiles" % (out, len(tiles), n64))
