@@ -109,7 +109,10 @@ int semseg_stem_conv_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_
  * ([2*C]) is exactly what SyncBN all-reduces. */
 int semseg_channel_stats(const float* x, int ldx, double* stats, int nslot, int M, int C,
                          hipStream_t stream);
-int semseg_bn_combine(double* stats, int nslot, int C, hipStream_t stream);
+/* dst[2*C] = sum over the nslot replicas (dst == NULL: into slot 0 of stats).  A SyncBN GROUP — BatchNorm layers whose
+ * statistics do not depend on each other (bn3 + downsample BN of a projection block, the four PPM branches, the cls /
+ * aux head BNs) — combines into adjacent pieces of ONE staging vector, which is all-reduced once. */
+int semseg_bn_combine(double* stats, int nslot, int C, double* dst, hipStream_t stream);
 int semseg_bn_finalize(const double* stats, int nslot, double count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, long long* num_batches_tracked,
                        float momentum, float eps, float* mean, float* invstd, float* scale,
@@ -131,9 +134,10 @@ int semseg_bn_bwd_reduce(const float* dout, int lddout, const float* out, int ld
 int semseg_bn_bwd_apply(const float* g, int ldg, const float* y, int ldy, const float* mean,
                         const float* invstd, const float* gamma, const double* sums, double count,
                         float* dy, int lddy, int M, int C, hipStream_t stream);
-/* combines the nslot replicas of sums into slot 0 and writes dgamma = sum g*xhat, dbeta = sum g */
+/* combines the nslot replicas of sums into `folded` ([2*C]; NULL: slot 0 of sums) and writes dgamma = sum g*xhat,
+ * dbeta = sum g from the LOCAL sums; `folded` is what the SyncBN backward all-reduces (per group, see above) */
 int semseg_bn_param_grads(double* sums, int nslot, float* dgamma, float* dbeta, int C,
-                          int accumulate, hipStream_t stream);
+                          int accumulate, double* folded, hipStream_t stream);
 
 /* ---- spatial ops: MaxPool2d(3,2,1) model/resnet.py:115; AdaptiveAvgPool2d model/pspnet.py:14;
  * F.interpolate(bilinear, align_corners=True) model/pspnet.py:25,95,100; model/psanet.py:61,78,97. */

@@ -104,12 +104,12 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 }
 
 // sums -> mean / invstd / scale / shift; running-stat update (train)
-__global__ void bn_combine_kernel(double* stats, int nslot, int C2) {
+__global__ void bn_combine_kernel(const double* stats, int nslot, int C2, double* dst) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C2) return;
   double v = stats[c];
   for (int s = 1; s < nslot; ++s) v += stats[(size_t)s * C2 + c];
-  stats[c] = v;
+  dst[c] = v;
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nslot, double count,
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdApplyArgs p)
 // combines the nslot partial vectors into slot 0 (what bn_bwd_apply / the SyncBN all-reduce read)
 // and emits the parameter gradients from the LOCAL sums
 __global__ void bn_param_grads_kernel(double* sums, int nslot, float* dgamma, float* dbeta,
-                                      int C, int accumulate) {
+                                      int C, int accumulate, double* folded) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = sums[c], s2 = sums[C + c];
@@ -351,8 +351,8 @@ __global__ void bn_param_grads_kernel(double* sums, int nslot, float* dgamma, fl
     s1 += sums[(size_t)s * 2 * C + c];
     s2 += sums[(size_t)s * 2 * C + C + c];
   }
-  sums[c] = s1;
-  sums[C + c] = s2;
+  folded[c] = s1;
+  folded[C + c] = s2;
   const float dg = (float)s2, db = (float)s1;
   dgamma[c] = accumulate ? dgamma[c] + dg : dg;
   dbeta[c] = accumulate ? dbeta[c] + db : db;
@@ -379,9 +379,9 @@ int semseg_channel_stats(const float* x, int ldx, double* stats, int nslot, int 
   return semseg_launch_status();
 }
 
-int semseg_bn_combine(double* stats, int nslot, int C, hipStream_t stream) {
+int semseg_bn_combine(double* stats, int nslot, int C, double* dst, hipStream_t stream) {
   if (!stats || nslot < 1) return SEMSEG_EINVAL;
-  bn_combine_kernel<<<(2 * C + 255) / 256, 256, 0, stream>>>(stats, nslot, 2 * C);
+  bn_combine_kernel<<<(2 * C + 255) / 256, 256, 0, stream>>>(stats, nslot, 2 * C, dst ? dst : stats);
   return semseg_launch_status();
 }
 
@@ -443,9 +443,10 @@ int semseg_bn_bwd_apply(const float* g, int ldg, const float* y, int ldy, const 
 }
 
 int semseg_bn_param_grads(double* sums, int nslot, float* dgamma, float* dbeta, int C,
-                          int accumulate, hipStream_t stream) {
+                          int accumulate, double* folded, hipStream_t stream) {
   if (!sums || !dgamma || !dbeta || nslot < 1) return SEMSEG_EINVAL;
-  bn_param_grads_kernel<<<(C + 255) / 256, 256, 0, stream>>>(sums, nslot, dgamma, dbeta, C, accumulate);
+  bn_param_grads_kernel<<<(C + 255) / 256, 256, 0, stream>>>(sums, nslot, dgamma, dbeta, C, accumulate,
+                                                            folded ? folded : sums);
   return semseg_launch_status();
 }
 

@@ -127,6 +127,27 @@ class BNL:
         self.eval_epoch = -1
 
 
+class SyncGroup:
+    """BatchNorm layers whose batch statistics do not depend on each other (bn3 + the downsample BN of a projection
+    block, the four PPM branches, the cls / aux head BNs): their [2C] fp64 vectors sit side by side in ONE staging
+    vector, so SyncBN needs one all-reduce per group and pass instead of one per layer (tool/train.py:142 converts
+    every BatchNorm to nn.SyncBatchNorm, each of which does its own exchange).  `todo` / `finish` defer the backward
+    of the members until the last one has delivered its sums."""
+
+    def __init__(self, bls, device):
+        self.bls = list(bls)
+        self.buf = torch.zeros(sum(2 * b.C for b in bls), dtype=F64, device=device)
+        self.views, off = {}, 0
+        for b in bls:
+            self.views[id(b)] = self.buf[off:off + 2 * b.C]
+            off += 2 * b.C
+        self.todo = 0
+        self.finish = []
+
+    def view(self, bl):
+        return self.views[id(bl)]
+
+
 class Engine:
     def __init__(self, model, N, H, W, training, kind):
         self.model = model
@@ -182,6 +203,8 @@ class Engine:
         self._labels_checked = False
         self._drop_calls = 0
         self.tape_hook = None  # callable(TapeOp) that must call op.fn(); set by tests only
+        self._groups = {}
+        self.syncbn_collectives_per_step = 0   # SyncBN all-reduces issued by the last forward + backward
 
     def push(self, kind, fn, **ctx):
         self.tape.append(TapeOp(kind, fn, ctx))
@@ -461,45 +484,78 @@ class Engine:
             if st != cur:
                 cur.wait_stream(st)
 
-    def _sync(self, t):
-        if (self.sync_bn or self.force_sync_bn) and self.dist_on:
-            dist.all_reduce(t)
-            return self.world
-        return 1
+    def _syncing(self):
+        return (self.sync_bn or self.force_sync_bn) and self.dist_on
+
+    def _all_reduce(self, t):
+        dist.all_reduce(t)
+        self.syncbn_collectives_per_step += 1
+
+    def _group(self, bls):
+        key = tuple(id(b) for b in bls)
+        g = self._groups.get(key)
+        if g is None:
+            g = self._groups[key] = SyncGroup(bls, self.device)
+        return g
 
     def bn_prepare(self, bm, count):
         """stats -> scale/shift (train: batch statistics, SyncBN all-reduce; eval: running stats)."""
-        bl = self.bns[bm]
-        if self.training and bm.training:
-            ns = ops.NSLOT
-            if (self.sync_bn or self.force_sync_bn) and self.dist_on:
-                ops.bn_combine(bl.stats, ns, bl.C)
-                dist.all_reduce(bl.stats[:2 * bl.C])
-                ns = 1
-                cnt = count * self.world
-            else:
-                cnt = count
-            if cnt <= 1:
-                raise ValueError("Expected more than 1 value per channel when training, got input "
-                                 "size [%d values per channel]" % cnt)
-            track = bm.track_running_stats and bm.running_mean is not None
-            ops.bn_finalize(bl.stats, cnt, bm.weight.detach(), bm.bias.detach(),
-                            bm.running_mean if track else None, bm.running_var if track else None,
-                            bm.num_batches_tracked if track else None, bl.momentum, bl.eps, bl.mean,
-                            bl.invstd, bl.scale, bl.shift, bl.C, nslot=ns)
-            return cnt
-        ops.bn_eval_params(bm.weight.detach(), bm.bias.detach(), bm.running_mean, bm.running_var, bl.eps,
-                           bl.scale, bl.shift, bl.C)
-        return 0
+        return self.bn_prepare_group([(bm, count)])[0]
 
-    def bn_act(self, y, bm, relu=True, res=None, y2=None, bm2=None, dropmask=None, out=None):
-        """out = [relu](bn(y) (+ bn2(y2)) (+ res)) (* dropmask)   — model/resnet.py:76-92."""
+    def bn_prepare_group(self, items):
+        """items: [(BatchNorm module, values per channel on this rank)] of layers whose statistics are all complete.
+        Under SyncBN the group's [sum, sum of squares] vectors are combined into one staging vector and all-reduced
+        ONCE.  Returns the global count per layer (0 for layers normalising with running statistics)."""
+        out = []
+        train = [(bm, c) for bm, c in items if self.training and bm.training]
+        if train and self._syncing():
+            bls = [self.bns[bm] for bm, _ in train]
+            if len(bls) == 1:
+                views = [bls[0].stats[:2 * bls[0].C]]
+                ops.bn_combine(bls[0].stats, ops.NSLOT, bls[0].C)
+                self._all_reduce(views[0])
+            else:
+                g = self._group(bls)
+                views = [g.view(bl) for bl in bls]
+                for bl, v in zip(bls, views):
+                    ops.bn_combine(bl.stats, ops.NSLOT, bl.C, dst=v)
+                self._all_reduce(g.buf)
+            src = {id(bm): (v, 1) for (bm, _), v in zip(train, views)}
+        else:
+            src = {id(bm): (self.bns[bm].stats, ops.NSLOT) for bm, _ in train}
+        for bm, count in items:
+            bl = self.bns[bm]
+            if id(bm) in src:
+                st, ns = src[id(bm)]
+                cnt = count * self.world if self._syncing() else count
+                if cnt <= 1:
+                    raise ValueError("Expected more than 1 value per channel when training, got input "
+                                     "size [%d values per channel]" % cnt)
+                track = bm.track_running_stats and bm.running_mean is not None
+                ops.bn_finalize(st, cnt, bm.weight.detach(), bm.bias.detach(),
+                                bm.running_mean if track else None, bm.running_var if track else None,
+                                bm.num_batches_tracked if track else None, bl.momentum, bl.eps, bl.mean,
+                                bl.invstd, bl.scale, bl.shift, bl.C, nslot=ns)
+                out.append(cnt)
+            else:
+                ops.bn_eval_params(bm.weight.detach(), bm.bias.detach(), bm.running_mean, bm.running_var, bl.eps,
+                                   bl.scale, bl.shift, bl.C)
+                out.append(0)
+        return out
+
+    def bn_act(self, y, bm, relu=True, res=None, y2=None, bm2=None, dropmask=None, out=None, prepared=None,
+               group=None):
+        """out = [relu](bn(y) (+ bn2(y2)) (+ res)) (* dropmask)   — model/resnet.py:76-92.
+        prepared / group: the caller already ran bn_prepare_group for this layer together with others (PPM branches,
+        the two heads); `group` defers this layer's backward until the group's one all-reduce."""
         bl = self.bns[bm]
-        cnt = self.bn_prepare(bm, y.M)
         bl2 = None
         if y2 is not None:
+            assert prepared is None
             bl2 = self.bns[bm2]
-            self.bn_prepare(bm2, y2.M)
+            cnt = self.bn_prepare_group([(bm, y.M), (bm2, y2.M)])[0]
+        else:
+            cnt = self.bn_prepare(bm, y.M) if prepared is None else prepared
         if out is None:
             out = self.act(y.N, y.H, y.W, y.C, tag="bnact")
         ops.bn_apply(y.data, y.ld, bl.scale, bl.shift, out.data, out.ld, y.M, y.C, y.H * y.W, relu,
@@ -512,12 +568,14 @@ class Engine:
                 out.bnsrc = dict(bns=[(y, bl)] + ([(y2, bl2)] if y2 is not None else []), relu=relu)
             if res is not None and res.fuse_ok:
                 res.pending += 1
-            self.push("bn_act", lambda: self._bn_act_bwd(y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt),
+            if group is not None:
+                group.todo += 1
+            self.push("bn_act", lambda: self._bn_act_bwd(y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt, group),
                       y=y, bm=bm, bl=bl, relu=relu, res=res, y2=y2, bm2=bm2, bl2=bl2, dropmask=dropmask, out=out,
                       cnt=cnt)
         return out
 
-    def _bn_act_bwd(self, y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt):
+    def _bn_act_bwd(self, y, bm, bl, relu, res, y2, bm2, bl2, dropmask, out, cnt, group=None):
         dout = out.grad
         assert dout is not None and out.ginit
         gy = self.grad_of(y)
@@ -540,23 +598,42 @@ class Engine:
                 g, ldg = gy, y.ld
             ops.bn_bwd_reduce(dout, out.ld, out.data if relu else None, out.ld, dropmask, y.H * y.W, y.data,
                               y.ld, bl.mean, bl.invstd, g, ldg, bl.sums, y.M, y.C, nslot=ops.NSLOT)
-        if y2 is not None:
-            if not out.bn_reduced:
+            if y2 is not None:
                 ops.bn_bwd_reduce(g, ldg, None, 0, None, y2.H * y2.W, y2.data, y2.ld, bl2.mean, bl2.invstd,
                                   None, 0, bl2.sums, y2.M, y2.C, nslot=ops.NSLOT)
-            ops.bn_param_grads(bl2.sums, bl2.ggrad, bl2.bgrad, bl2.C, nslot=ops.NSLOT)
-            self._sync(bl2.sums[:2 * bl2.C])
-            gy2 = self.grad_of(y2)
-            ops.bn_bwd_apply(g, ldg, y2.data, y2.ld, bl2.mean, bl2.invstd, bm2.weight.detach(), bl2.sums,
-                             cnt, gy2, y2.ld, y2.M, y2.C)
-            y2.ginit = True
-            self._ready([bm2.weight, bm2.bias])
-        ops.bn_param_grads(bl.sums, bl.ggrad, bl.bgrad, bl.C, nslot=ops.NSLOT)
-        self._sync(bl.sums[:2 * bl.C])
-        ops.bn_bwd_apply(g, ldg, y.data, y.ld, bl.mean, bl.invstd, bm.weight.detach(), bl.sums, cnt, gy,
-                         y.ld, y.M, y.C)
-        y.ginit = True
-        self._ready([bm.weight, bm.bias])
+        members = ([(y2, bm2, bl2)] if y2 is not None else []) + [(y, bm, bl)]
+        sync = self._syncing()
+        if sync and group is None and len(members) > 1:
+            group = self._group([bl, bl2])    # bn3 + downsample BN: a group that is complete within this op
+            group.todo = 1
+        if not sync:
+            group = None
+        # parameter gradients come from the LOCAL sums (torch SyncBatchNorm semantics); the folded [2C] vector — what
+        # the input gradient needs summed over all ranks — lands in slot 0 or in the group's staging piece
+        for yy, bmm, bll in members:
+            ops.bn_param_grads(bll.sums, bll.ggrad, bll.bgrad, bll.C, nslot=ops.NSLOT,
+                               folded=None if group is None else group.view(bll))
+
+        def finish():
+            for yy, bmm, bll in members:
+                ops.bn_bwd_apply(g, ldg, yy.data, yy.ld, bll.mean, bll.invstd, bmm.weight.detach(),
+                                 bll.sums if group is None else group.view(bll), cnt, self.grad_of(yy), yy.ld, yy.M,
+                                 yy.C)
+                yy.ginit = True
+                self._ready([bmm.weight, bmm.bias])
+
+        if group is None:
+            if sync:
+                self._all_reduce(bl.sums[:2 * bl.C])
+            finish()
+        else:
+            group.finish.append(finish)
+            group.todo -= 1
+            if group.todo == 0:
+                self._all_reduce(group.buf)
+                fs, group.finish = group.finish, []
+                for f in fs:
+                    f()
 
     # ------------------------------------------------------------------ network pieces
     def stem(self, x_nchw):
@@ -653,10 +730,22 @@ class Engine:
         c0 = C
         for f, b in zip(feats, bins):
             n = N * b * b * C
-            pa = Act(pooled[off:off + n].view(N, b, b, C), N, b, b, C, C, "pooled%d" % b)
+            pacts.append(Act(pooled[off:off + n].view(N, b, b, C), N, b, b, C, C, "pooled%d" % b))
             off += n
-            pacts.append(pa)
-            ab = self.conv_bn(pa, f[1], f[2])
+        ys = cnts = grp = None
+        if self.training:
+            # the four branch convs first: their BatchNorm statistics do not depend on each other, so under SyncBN
+            # they travel in ONE all-reduce per pass (bn_prepare_group) instead of four
+            ys = [self.conv(pa, f[1], stats=self._st(f[2])) for pa, f in zip(pacts, feats)]
+            cnts = self.bn_prepare_group([(f[2], yb.M) for f, yb in zip(feats, ys)])
+            if self._syncing() and all(f[2].training for f in feats):
+                grp = self._group([self.bns[f[2]] for f in feats])
+        for i, (f, b) in enumerate(zip(feats, bins)):
+            pa = pacts[i]
+            if self.training:
+                ab = self.bn_act(ys[i], f[2], prepared=cnts[i], group=grp)
+            else:
+                ab = self.conv_bn(pa, f[1], f[2])
             dst = cat.slice(c0, ab.C)
             ops.bilinear_fwd(ab.data, ab.ld, dst.data, dst.ld, N, b, b, H, W, ab.C)
             if self.training:
@@ -698,6 +787,29 @@ class Engine:
         out = self.act(x.N, x.H, x.W, ncls, ld=ops.roundup(ncls, 128), tag="scores" + tag)
         return self.conv(a, conv_b, out=out, bias=True)
 
+    def heads_train(self, feat, x_tmp):
+        """cls and aux heads of a training step (model/pspnet.py:96-103).  Same layers as head(), but both 3x3 convs
+        run before either BatchNorm: the two BatchNorms then share one SyncBN all-reduce per pass."""
+        hs = []
+        for x, seq in ((feat, self.model.cls), (x_tmp, self.model.aux)):
+            conv_a, bn_a, drop = seq[0], seq[1], seq[3]
+            dm = None
+            if drop.training and drop.p > 0:
+                dm = self.buf((x.N, conv_a.weight.shape[0]), tag="dropmask")
+                self._drop_calls += 1
+                ops.dropout2d_mask(dm, drop.p, torch.initial_seed(), self._drop_calls)
+            hs.append((self.conv(x, conv_a, stats=self._st(bn_a)), dm))
+        bns = [self.model.cls[1], self.model.aux[1]]
+        cnts = self.bn_prepare_group([(bm, yh.M) for bm, (yh, _) in zip(bns, hs)])
+        grp = self._group([self.bns[bm] for bm in bns]) if (self._syncing() and all(b.training for b in bns)) else None
+        outs = []
+        for seq, bm, (yh, dm), cnt, tag in zip((self.model.cls, self.model.aux), bns, hs, cnts, ("m", "a")):
+            a = self.bn_act(yh, bm, dropmask=dm, prepared=cnt, group=grp)
+            ncls = seq[4].weight.shape[0]
+            out = self.act(yh.N, yh.H, yh.W, ncls, ld=ops.roundup(ncls, 128), tag="scores" + tag)
+            outs.append(self.conv(a, seq[4], out=out, bias=True))
+        return outs
+
     def ce(self, scores, label, H, W, ignore_index, want_pred, tag):
         N = scores.N
         lse = self.buf((N, H, W), tag="lse" + tag)
@@ -733,6 +845,9 @@ class Engine:
             self.weights_version = sig
         if self.training:
             ops.zero_(self._f64_arena)
+            self.syncbn_collectives_per_step = 0
+            for g in self._groups.values():
+                g.todo, g.finish = 0, []
             self.model.__dict__["_hip_bn_epoch"] = self.model.__dict__.get("_hip_bn_epoch", 0) + 1
         else:
             # eval-mode scale/shift are cached until the weights, the running statistics (torch-side
@@ -793,8 +908,7 @@ class Engine:
                                  % (nbad, ignore_index, self.model.cls[4].weight.shape[0]))
             self._labels_checked = True
         x_tmp, feat = self._features(x)
-        scores = self.head(feat, self.model.cls, "m")
-        aux = self.head(x_tmp, self.model.aux, "a")
+        scores, aux = self.heads_train(feat, x_tmp)
         main_loss, pred, self._rec_main = self.ce(scores, y, h, w, ignore_index, True, "m")
         aux_loss, _, self._rec_aux = self.ce(aux, y, h, w, ignore_index, False, "a")
         return pred, main_loss, aux_loss

@@ -230,8 +230,8 @@ def channel_stats(x, ldx, stats, M, C, nslot=1):
     _ck(lib.semseg_channel_stats(_p(x), ldx, _p(stats), nslot, M, C, _stream()), "channel_stats")
 
 
-def bn_combine(stats, nslot, C):
-    _ck(lib.semseg_bn_combine(_p(stats), nslot, C, _stream()), "bn_combine")
+def bn_combine(stats, nslot, C, dst=None):
+    _ck(lib.semseg_bn_combine(_p(stats), nslot, C, _p(dst), _stream()), "bn_combine")
 
 
 def bn_finalize(stats, count, gamma, beta, rm, rv, nbt, momentum, eps, mean, invstd, scale, shift, C,
@@ -265,9 +265,9 @@ def bn_bwd_apply(g, ldg, y, ldy, mean, invstd, gamma, sums, count, dy, lddy, M, 
                                 float(count), _p(dy), lddy, M, C, _stream()), "bn_bwd_apply")
 
 
-def bn_param_grads(sums, dgamma, dbeta, C, accumulate=False, nslot=1):
-    _ck(lib.semseg_bn_param_grads(_p(sums), nslot, _p(dgamma), _p(dbeta), C, int(accumulate), _stream()),
-        "bn_param_grads")
+def bn_param_grads(sums, dgamma, dbeta, C, accumulate=False, nslot=1, folded=None):
+    _ck(lib.semseg_bn_param_grads(_p(sums), nslot, _p(dgamma), _p(dbeta), C, int(accumulate), _p(folded),
+                                  _stream()), "bn_param_grads")
 
 
 # ---------------------------------------------------------------------------------------------

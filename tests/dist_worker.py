@@ -46,8 +46,9 @@ def run(world, rank, steps=2, bucket_mb=8):
             w_first = tr.flat_w.cpu().numpy()
     torch.cuda.synchronize()
     sd = m.state_dict()
+    ncoll = max(e.syncbn_collectives_per_step for e in tr.engines.values())
     return np.array(losses), tr.flat_w.cpu().numpy(), sd["layer0.1.running_var"].cpu().numpy(), \
-        sd["cls.1.running_mean"].cpu().numpy(), w_first
+        sd["cls.1.running_mean"].cpu().numpy(), w_first, ncoll
 
 
 if __name__ == "__main__":
@@ -56,8 +57,9 @@ if __name__ == "__main__":
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    losses, w, rv, rm, w1 = run(world, rank, steps=int(os.environ.get("STEPS", "2")))
-    np.savez(os.path.join(out, "rank%d_of%d.npz" % (rank, world)), losses=losses, w=w, rv=rv, rm=rm, w1=w1)
+    losses, w, rv, rm, w1, ncoll = run(world, rank, steps=int(os.environ.get("STEPS", "2")))
+    np.savez(os.path.join(out, "rank%d_of%d.npz" % (rank, world)), losses=losses, w=w, rv=rv, rm=rm, w1=w1,
+             ncoll=ncoll)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

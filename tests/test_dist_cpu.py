@@ -71,6 +71,50 @@ def test_syncbn_protocol_world2():
     assert res == [(0, True, True), (1, True, True)], res
 
 
+def _group_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from semseg_amd.engine import SyncGroup
+
+        class _BL:
+            def __init__(self, C):
+                self.C = C
+        bls = [_BL(8), _BL(16), _BL(4)]
+        g = SyncGroup(bls, torch.device("cpu"))
+        gen = torch.Generator().manual_seed(100 + rank)
+        local = [torch.randn(2 * b.C, generator=gen, dtype=torch.float64) for b in bls]
+        for b, v in zip(bls, local):
+            g.view(b).copy_(v)
+        # views are adjacent pieces of ONE vector in member order
+        ok_layout = g.buf.numel() == 56 and all(g.view(b).data_ptr() == g.buf.data_ptr() + 8 * o
+                                                for b, o in zip(bls, (0, 16, 48)))
+        dist.all_reduce(g.buf)                      # one exchange for the group ...
+        sep = [v.clone() for v in local]
+        for v in sep:
+            dist.all_reduce(v)                      # ... equals one exchange per layer
+        ok_sum = all(torch.equal(g.view(b), v) for b, v in zip(bls, sep))
+        q.put((rank, bool(ok_layout), bool(ok_sum)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_group_staging_world2():
+    """One all-reduce of a SyncGroup's staging vector == one all-reduce per BatchNorm layer (bitwise: the same two
+    addends per element)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True, True), (1, True, True)], res
+
+
 def test_gradient_buckets_cover_parameters_once():
     from model.pspnet import PSPNet
     from semseg_amd.trainer import Trainer

@@ -77,6 +77,9 @@ def test_two_ranks_equal_single_process(report):
            % (e_loss, e_w, e_rv, e_rm))
     # weights: two fp32 runs with different batch splits differ by ReLU-mask flips (see test_model_gpu.run_case)
     assert e_loss < 1e-5 and e_w < 2e-3 and e_rv < 1e-4 and e_rm < 1e-4
+    # SyncBN exchanges per step: PSPNet-50 has 61 BatchNorm layers; bn3 + downsample BN of the 4 projection blocks, the
+    # 4 PPM branches and the 2 heads share an all-reduce each -> 61 - 4 - 3 - 1 = 53 per pass, forward + backward
+    assert int(r0["ncoll"]) == 106 and int(one["ncoll"]) == 0, (r0["ncoll"], one["ncoll"])
 
 
 def test_reference_train_wrapping_sequence(report):
