@@ -37,7 +37,11 @@ class PSAMask(Function):
         geo = _geometry(input, psa_type, mask_H_, mask_W_)
         n, chans, fh, fw, mh, mw, hh, hw = geo
         _check(input, "input")
-        output = torch.zeros((n, fh * fw, fh, fw), dtype=input.dtype, device=input.device)
+        # psamask.py:17 zero-fills the output because the kernel only writes in-window elements.  With a full-size mask
+        # (mask >= 2 * feature - 1, the default) EVERY element is in the window and is written exactly once, so the
+        # 4 * N * (H*W)^2-byte memset is skipped; smaller masks keep the zero fill.
+        full = mh >= 2 * fh - 1 and mw >= 2 * fw - 1
+        output = (torch.empty if full else torch.zeros)((n, fh * fw, fh, fw), dtype=input.dtype, device=input.device)
         src.gpu.psamask_forward(psa_type, input.contiguous(), output, n, fh, fw, mh, mw, hh, hw)
         ctx.cfg = (psa_type,) + geo
         return output

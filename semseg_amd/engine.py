@@ -127,6 +127,23 @@ class BNL:
         self.eval_epoch = -1
 
 
+# HIP streams (and the split-K scratch arenas that go with them) are shared by every engine of a process, per device.
+# The runtime multiplexes streams onto a handful of hardware queues round-robin: when each engine created its own
+# side / high-priority streams, the streams of the SECOND engine of a process (another input shape, an eval engine, the
+# module path after the Trainer in bench.py) could land on one hardware queue, and its backward lost the concurrency
+# of the weight-gradient stream with the dependent chain (measured: 207 ms for the first engine of a process, 221-230
+# ms for an identical second one).  Engines of one process never run concurrently, so sharing is safe.
+_SHARED = {}
+
+
+def _shared(device, name, make):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), name)
+    v = _SHARED.get(key)
+    if v is None:
+        v = _SHARED[key] = make()
+    return v
+
+
 class SyncGroup:
     """BatchNorm layers whose batch statistics do not depend on each other (bn3 + the downsample BN of a projection
     block, the four PPM branches, the cls / aux head BNs): their [2C] fp64 vectors sit side by side in ONE staging
@@ -173,7 +190,6 @@ class Engine:
         self._f64_cap = 0
         self._register()
         self._flat_grads()
-        self.wgrad_scratch = None
         self.grads_ready_hook = None  # callable(param_list) fired as parameter gradients complete
         self.weights_version = None
         self.ktimer = None
@@ -435,18 +451,21 @@ class Engine:
     def _side_stream(self):
         """Next weight-gradient stream (round-robin over n_side) and its private split-K scratch."""
         while len(self._sides) < max(1, self.n_side):
-            self._sides.append(torch.cuda.Stream(device=self.device))
-            self._scr2s.append(torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device))
+            i = len(self._sides)
+            self._sides.append(_shared(self.device, "side%d" % i, lambda: torch.cuda.Stream(device=self.device)))
+            self._scr2s.append(_shared(self.device, "side_scratch%d" % i,
+                                       lambda: torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device)))
         i = self._side_rr % max(1, self.n_side)
         self._side_rr += 1
         self._side = self._sides[0]
         return self._sides[i], self._scr2s[i]
 
     def scratch(self):
-        """256 MB arena for split-K partial slabs (conv fwd/dgrad at small batch, every wgrad)."""
-        if self.wgrad_scratch is None:
-            self.wgrad_scratch = torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device)
-        return self.wgrad_scratch
+        """256 MB arena for split-K partial slabs (conv fwd/dgrad at small batch, every wgrad), one per stream that
+        work is issued on (shared by the engines of the process: work on one stream is ordered)."""
+        st = torch.cuda.current_stream(self.device)
+        return _shared(self.device, "scratch@%x" % st.cuda_stream,
+                       lambda: torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device))
 
     def _t0(self, family, flops):
         if self.ktimer is None:
@@ -919,7 +938,7 @@ class Engine:
         self._f64_zero_sums()
         if self.hipri_main:
             if self._hi is None:
-                self._hi = torch.cuda.Stream(device=self.device, priority=-1)
+                self._hi = _shared(self.device, "hipri", lambda: torch.cuda.Stream(device=self.device, priority=-1))
             cur = torch.cuda.current_stream()
             self._hi.wait_stream(cur)
             with torch.cuda.stream(self._hi):

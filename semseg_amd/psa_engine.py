@@ -75,15 +75,14 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
             gz = zcat.grad[..., zoff:]
             daff = eng.buf((N * hw + PADROWS, P), zero=True, tag="psa_daff")
             gxs = eng.grad_of(xs)
-            if eng.wgrad_scratch is None:
-                eng.wgrad_scratch = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=eng.device)
+            scr = eng.scratch()
             # dA[n][q,p] = sum_c dz[q,c] x[p,c]   (B^T rows = p, K = c: x in its native layout), all images at once
             ev = eng._t0("conv_igemm_kernel<128,128,false,1>(+splitk_epilogue)", gflops)
             ops.gemm_rows_batched(gz, zcat.ld, hw * zcat.ld, xs.data, hw * xs.ld, daff, P, hw * P, hw, C, hw, N)
             eng._t1(ev)
             ev = eng._t0("conv_wgrad_dma_kernel<128x128>+reduce", gflops)
             # dx[n][p,c] = sum_q A[q,p] dz[q,c]   (K-major GEMM, all images at once)
-            ops.gemm_kmajor_batched(gz, zcat.ld, hw * zcat.ld, aff, P, hw * P, gxs, hw * xs.ld, eng.wgrad_scratch,
+            ops.gemm_kmajor_batched(gz, zcat.ld, hw * zcat.ld, aff, P, hw * P, gxs, hw * xs.ld, scr,
                                     hw, C, hw, N, accumulate=xs.ginit)
             eng._t1(ev)
             xs.ginit = True

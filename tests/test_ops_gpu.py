@@ -476,14 +476,16 @@ def test_sgd(report):
     assert e < 1e-6
 
 
-@pytest.mark.parametrize("H,W,mH,mW", [(5, 5, 9, 9), (5, 7, 9, 13), (6, 6, 5, 5), (4, 4, 3, 3),
-                                      (30, 30, 59, 59)])
+@pytest.mark.parametrize("H,W,mH,mW", [(5, 5, 9, 9), (5, 7, 9, 13), (6, 6, 5, 5), (4, 4, 3, 3), (7, 6, 5, 11),
+                                      (3, 8, 9, 5), (1, 1, 1, 1), (30, 30, 59, 59), (45, 45, 89, 89), (70, 70, 9, 139)])
 def test_psamask_vs_oracle(H, W, mH, mW, report):
-    """Bit-exact against the C oracle (restatement of lib/psa/src/cpu/psamask.cpp)."""
+    """Bit-exact against the C oracle (restatement of lib/psa/src/cpu/psamask.cpp): full-size, small, non-square and
+    even-width masks, the two PSANet shapes (30^2 / 59^2 at 465 px, 45^2 / 89^2 at 705 px) and a shape past the
+    plane-group kernel's largest instance (falls back to the slab kernel)."""
     import numpy as np
     from oracle import psamask as orc
     from semseg_amd import ops
-    N = 2
+    N = 2 if H < 40 else 1
     rng = np.random.default_rng(H * 1000 + mW)
     x = rng.standard_normal((N, mH * mW, H, W)).astype(np.float32)
     gy = rng.standard_normal((N, H * W, H, W)).astype(np.float32)
