@@ -33,11 +33,13 @@ for name, H, Ci, Co, k, s, p, d, cnt in SHAPES:
     pk = ops.PackedConv(Co, Ci, k, k, dev)
     w = torch.randn(Co, Ci, k, k, device=dev) * 0.05
     pk.pack(w)
-    x = torch.randn(N, H, W, Ci, device=dev)
-    ldy = Co if Co % 64 == 0 else ops.roundup(Co, 128)
+    LDXP, LDYP = int(os.environ.get("LDX_PAD", "0")), int(os.environ.get("LDY_PAD", "0"))
+    ldx = Ci + LDXP
+    x = torch.randn(N, H, W, ldx, device=dev)
+    ldy = (Co if Co % 64 == 0 else ops.roundup(Co, 128)) + LDYP
     y = torch.zeros(N, Ho, Ho, ldy, device=dev)
     dy = torch.zeros(N, Ho, Ho, ldy, device=dev); dy[..., :Co].normal_()
-    dx = torch.empty(N, H, W, Ci, device=dev)
+    dx = torch.empty(N, H, W, ldx, device=dev)
     dw = torch.empty(Co, Ci, k, k, device=dev)
     stats8 = torch.zeros(2 * Co * ops.NSLOT, dtype=torch.float64, device=dev)
     fl = 2.0 * N * Ho * Ho * Co * Ci * k * k
@@ -49,9 +51,9 @@ for name, H, Ci, Co, k, s, p, d, cnt in SHAPES:
         e_.record(); torch.cuda.synchronize()
         return s_.elapsed_time(e_) / it * 1e3
     st_arg = None if os.environ.get('NOSTATS') else stats8
-    tf = timeit(lambda: ops.conv_fwd(x, Ci, pk, y, ldy, N, H, W, s, p, d, stats=st_arg, nslot=ops.NSLOT, scratch=scratch))
-    td = timeit(lambda: ops.conv_dgrad(dy, ldy, pk, dx, Ci, N, H, W, s, p, d, scratch=scratch))
-    tw = timeit(lambda: ops.conv_wgrad(x, Ci, dy, ldy, dw, scratch, N, H, W, Ci, Co, k, k, s, p, d))
+    tf = timeit(lambda: ops.conv_fwd(x, ldx, pk, y, ldy, N, H, W, s, p, d, stats=st_arg, nslot=ops.NSLOT, scratch=scratch))
+    td = timeit(lambda: ops.conv_dgrad(dy, ldy, pk, dx, ldx, N, H, W, s, p, d, scratch=scratch))
+    tw = timeit(lambda: ops.conv_wgrad(x, ldx, dy, ldy, dw, scratch, N, H, W, Ci, Co, k, k, s, p, d))
     print("%-28s %8.1f | %8.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f" % (name, fl / 1e9, tf, fl / tf / 1e6, td, fl / td / 1e6, tw, fl / tw / 1e6))
     tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt
 print("weighted totals (ms):", {k: round(v / 1e3, 2) for k, v in tot.items()})

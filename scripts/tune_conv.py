@@ -4,9 +4,9 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "semseg_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_variants")
-VARIANTS = {   # last used set; earlier sets are listed in DESIGN.md section 8.1
-    "base_a": [],      # add {"name": ["-DKNOB=value"]} entries for the experiment at hand; the product source carries
-    "base_b": [],      # no knobs any more (round 3), so a knob lives only as long as its experiment
+VARIANTS = {
+    "base": [],
+    "occ4": ["-DEXP_OCC4=1"],
 }
 SRCS = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip", "psa_ops.hip", "infer.hip", "optim.hip", "augment.hip"]
 if sys.argv[1] == "build":
@@ -22,5 +22,5 @@ else:
     for tag in VARIANTS:
         env = dict(os.environ, SEMSEG_HIP_LIB=os.path.join(OUT, "lib_%s.so" % tag))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "conv_bench.py")], env=env, capture_output=True, text=True)
-        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("l1 conv", "l3 conv1", "l3 conv3", "l4 conv1", "l4 conv3", "weighted"))]
+        lines = [l for l in r.stdout.split("\n") if any(k in l for k in ("l1 conv", "l3 conv", "l4 conv", "cls.0", "aux.0", "weighted"))]
         print("==", tag); print("\n".join(lines)); sys.stdout.flush()
