@@ -96,6 +96,27 @@ int semseg_gemm_kmajor_batched(const float* x, int ldx, long long x_bs, const fl
                                float* out, long long out_bs, float* scratch, size_t scratch_floats, int K, int Ci,
                                int Co, int accumulate, int batch, hipStream_t stream);
 
+/* ---- Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convolutions (kernel 3, stride 1, padding = dilation:
+ * model/resnet.py:63-69 as modified by model/pspnet.py:49-58; head convs model/pspnet.py:65,73).
+ *   forward:        V = input_transform(x);  M[e] = V[e] * U[e]^T (semseg_gemm_rows_batched, batch 16);  y = output_transform(M)
+ *   data gradient:  the same three steps on dy with the flipped, transposed filter (filter_transform flip = 1)
+ *   weight gradient: Yh = dy_transform_wgrad(dy);  dU[e] = Yh[e]^T V[e] (semseg_gemm_kmajor_batched);  dw = filter_grad(dU)
+ * T = semseg_wino_tiles(N, H, W, dil) 2x2 output tiles (cut per dilation phase); V is [16][T][C], U [16][rows_pad][Kc],
+ * M [16][T][ldm], dU [16][Co][Ci].  1 / 2.25 of the direct convolution's multiplications, all in fp32. */
+int semseg_wino_tiles(int N, int H, int W, int dil);
+int semseg_wino_input_transform(const float* src, int lds, float* V, int N, int H, int W, int C, int dil,
+                                hipStream_t stream);
+int semseg_wino_dy_transform_wgrad(const float* dy, int lddy, float* Yh, int ldo, int N, int H, int W, int C, int dil,
+                                   hipStream_t stream);
+/* y = A^T M A (+ add); stats (optional, [nslot][2*C] fp64, caller-zeroed) += {sum y, sum y^2} of the values before add */
+int semseg_wino_output_transform(const float* M, int ldm, float* y, int ldy, const float* add, int ldadd, double* stats,
+                                 int nslot, int N, int H, int W, int C, int dil, hipStream_t stream);
+/* flip 0: U[e][co][ci] (rows_pad >= Co, Kc >= Ci);  flip 1: U[e][ci][co] with taps rotated 180 degrees (rows_pad >= Ci,
+ * Kc >= Co); padding rows / columns are written as zero */
+int semseg_wino_filter_transform(const float* w_oihw, float* U, int Co, int Ci, int rows_pad, int Kc, int flip,
+                                 hipStream_t stream);
+int semseg_wino_filter_grad(const float* dU, float* dw_oihw, int Co, int Ci, int accumulate, hipStream_t stream);
+
 /* Stem conv 3->64, 3x3 stride 2 pad 1, reading the caller's NCHW input (model/resnet.py:108). */
 int semseg_stem_conv_fwd(const float* x_nchw, const float* w_oihw, float* y_nhwc, int N, int H,
                          int W, int Co, hipStream_t stream);

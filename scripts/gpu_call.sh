@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-python scripts/tune_conv.py run 2>&1
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -12

@@ -100,13 +100,29 @@ class Act:
         return a
 
 
+WINOGRAD = os.environ.get("SEMSEG_WINOGRAD", "1") != "0"   # 0: every 3x3 conv on the direct implicit-GEMM kernels (A/B)
+
+
 class ConvL:
-    def __init__(self, mod, device, need_dgrad=True):
+    def __init__(self, mod, device, need_dgrad=True, training=True):
         w = mod.weight
         self.mod = mod
         self.Co, self.Ci, self.R, self.S = w.shape
         self.stride, self.pad, self.dil = mod.stride[0], mod.padding[0], mod.dilation[0]
-        self.pk = ops.PackedConv(self.Co, self.Ci, self.R, self.S, device, need_dgrad)
+        # Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convs of a TRAINING engine (csrc/winograd.hip): 1 / 2.25 of the
+        # multiplications, the 16 GEMMs as one batched matrix-core launch.  Measured per shape at bs 16
+        # (scripts/wino_bench.py, forward / data gradient / weight gradient, us): cls.0 15170 / 15240 / 17280 -> 8330 /
+        # 8420 / 7130, layer4 conv2 1957 / 1948 / 2155 -> 1343 / 1295 / 1367, layer3 conv2 608 / 616 / 613 -> 427 / 393 /
+        # 341; below 128 channels the transforms (HBM-bound) eat the gain (layer1 conv2: 152 -> 231), so those stay
+        # direct.  Channel counts: K % 64 for the K-major GEMM, Co % 128 so that no padded column exists.
+        # Eval engines fold BatchNorm / ReLU / the residual into the direct kernel's epilogue and stay direct.
+        self.wino = None
+        if (WINOGRAD and training and self.R == 3 and self.S == 3 and self.stride == 1 and self.pad == self.dil
+                and self.Ci % 64 == 0 and self.Ci >= 128 and self.Co % 128 == 0 and mod.bias is None):
+            self.wino = ops.WinoConv(self.Co, self.Ci, device, need_dgrad)
+            self.pk = None
+        else:
+            self.pk = ops.PackedConv(self.Co, self.Ci, self.R, self.S, device, need_dgrad)
         self.wgrad = None
         self.bgrad = None
 
@@ -261,7 +277,7 @@ class Engine:
                     self.convs[m] = None  # stem: direct kernel, no packed panel
                 else:
                     # eval engines never run a data-gradient: no second packed panel (halves their weight copy)
-                    self.convs[m] = ConvL(m, self.device, need_dgrad=self.training)
+                    self.convs[m] = ConvL(m, self.device, need_dgrad=self.training, training=self.training)
             elif isinstance(m, nn.modules.batchnorm._BatchNorm):
                 self.bns[m] = BNL(m, self)
 
@@ -310,7 +326,12 @@ class Engine:
         """One launch packs every conv weight (forward + data-gradient panels)."""
         import ctypes
         import numpy as np
-        items = [(m, cl) for m, cl in self.convs.items() if cl is not None]
+        for m, cl in self.convs.items():
+            if cl is not None and cl.wino is not None:
+                cl.wino.transform(m.weight.detach())
+        items = [(m, cl) for m, cl in self.convs.items() if cl is not None and cl.pk is not None]
+        if not items:
+            return
         ptrs = tuple(m.weight.data_ptr() for m, _ in items)
         if getattr(self, "_pack_ptrs", None) != ptrs:
             class Desc(ctypes.Structure):
@@ -367,6 +388,19 @@ class Engine:
         if out is None:
             ld = cl.Co if cl.Co % 64 == 0 else ops.roundup(cl.Co, 128)
             out = self.act(x.N, Ho, Wo, cl.Co, ld=ld, tag="conv")
+        if cl.wino is not None:
+            assert fold is None and not bias and self.training
+            T = ops.wino_tiles(x.N, x.H, x.W, cl.dil)
+            V = self.buf((16 * T * cl.Ci,), tag="winoV")      # kept: the weight gradient contracts it with dy
+            ev = self._t0("winograd F(2x2,3x3) fwd: transforms + batched conv_igemm_kernel<128,128,false,1>",
+                          2.0 * 16 * T * cl.Co * cl.Ci)
+            ops.wino_conv_fwd(x.data, x.ld, cl.wino, out.data, out.ld, x.N, x.H, x.W, cl.dil, V,
+                              self._wino_scratch("M", 16 * T * max(cl.Ci, cl.Co)), stats=stats, nslot=ops.NSLOT)
+            self._t1(ev)
+            if x.fuse_ok:
+                x.pending += 1
+            self.push("conv", lambda: self._conv_bwd_wino(x, out, cl, m, V, T), x=x, y=out, cl=cl, m=m)
+            return out
         tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld)
         ev = self._t0("conv_igemm_kernel<128,%d,false,%d>(+splitk_epilogue)" % (tile, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
         if fold is not None:
@@ -445,6 +479,52 @@ class Engine:
             else:
                 ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
                                add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
+            self._t1(ev)
+            x.ginit = True
+
+    def _wino_scratch(self, name, floats):
+        """Scratch of the Winograd path (products M, transformed dy, dU), shared by the engines of the process and
+        grown on demand; each name is used from one stream only (M / Vdy: the dependent chain, Yh / dU: the
+        weight-gradient stream), so reuse is ordered."""
+        key = (self.device.index if self.device.index is not None else torch.cuda.current_device(), "wino_" + name)
+        t = _SHARED.get(key)
+        if t is None or t.numel() < floats:
+            if t is not None:
+                torch.cuda.synchronize(self.device)     # a larger shape arrived: nothing may still read the old arena
+            t = _SHARED[key] = (torch.zeros if name == "Yh" else torch.empty)(floats, dtype=F32, device=self.device)
+        return t
+
+    def _conv_bwd_wino(self, x, y, cl, m, V, T):
+        """Backward of a Winograd conv: weight gradient dU[e] = Yh[e]^T V[e] on the side stream (one batched K-major GEMM,
+        V kept from forward), data gradient = the forward machinery on dy with the flipped filter on the main chain."""
+        dy = y.grad
+        assert dy is not None
+        N, H, W, d = x.N, x.H, x.W, cl.dil
+        gflops = 2.0 * 16 * T * cl.Co * cl.Ci
+
+        def wgrad(scr):
+            ev = self._t0("winograd F(2x2,3x3) wgrad: transforms + batched conv_wgrad_dma_kernel<128x128>+reduce", gflops)
+            ops.wino_conv_wgrad(V, dy, y.ld, cl.wino, cl.wgrad, N, H, W, d,
+                                self._wino_scratch("Yh", 16 * T * cl.Co), self._wino_scratch("dU", 16 * cl.Co * cl.Ci), scr)
+            self._t1(ev)
+            self._ready([m.weight])
+
+        if self.side_wgrad:
+            st, scr = self._side_stream()
+            st.wait_stream(torch.cuda.current_stream())
+            self._side_used = True
+            with torch.cuda.stream(st):
+                wgrad(scr)
+        else:
+            wgrad(self.scratch())
+        if x.name != "input":
+            gx = self.grad_of(x)
+            if x.fuse_ok:
+                x.pending -= 1      # no fused BatchNorm-backward reduction on this path: _bn_act_bwd runs its own pass
+            ev = self._t0("winograd F(2x2,3x3) dgrad: transforms + batched conv_igemm_kernel<128,128,false,1>", gflops)
+            ops.wino_conv_dgrad(dy, y.ld, cl.wino, gx, x.ld, N, H, W, d, self._wino_scratch("Vdy", 16 * T * cl.wino.Kc),
+                                self._wino_scratch("M", 16 * T * max(cl.Ci, cl.Co)),
+                                add=gx if x.ginit else None, ldadd=x.ld)
             self._t1(ev)
             x.ginit = True
 

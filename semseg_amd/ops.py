@@ -200,6 +200,90 @@ def conv_dgrad_bnreduce(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, act, 
                                        _stream()), "conv_dgrad_bnreduce")
 
 
+# ---------------------------------------------------------------------------------------------
+# Winograd F(2x2, 3x3): 3x3, stride 1, padding = dilation (include/semseg_hip.h)
+# ---------------------------------------------------------------------------------------------
+class WinoConv:
+    """Transformed filter panels of one 3x3 conv: U_fwd [16][Co_pad][Ci], U_dgrad [16][Ci_pad][Kc] (Kc = roundup(Co, 32))."""
+
+    def __init__(self, Co, Ci, device, need_dgrad=True):
+        self.Co, self.Ci = Co, Ci
+        self.Co_pad = roundup(Co, 128 if Co >= 128 else 64)
+        self.Ci_pad = roundup(Ci, 128 if Ci >= 128 else 64)
+        self.Kc = roundup(Co, 32)
+        self.U_fwd = torch.empty(16 * self.Co_pad * Ci, dtype=torch.float32, device=device)
+        self.U_dgrad = (torch.empty(16 * self.Ci_pad * self.Kc, dtype=torch.float32, device=device)
+                        if need_dgrad else None)
+
+    def transform(self, w_oihw):
+        _f32(w_oihw)
+        assert w_oihw.is_contiguous() and tuple(w_oihw.shape) == (self.Co, self.Ci, 3, 3)
+        _ck(lib.semseg_wino_filter_transform(_p(w_oihw), _p(self.U_fwd), self.Co, self.Ci, self.Co_pad, self.Ci, 0,
+                                             _stream()), "wino_filter_transform")
+        if self.U_dgrad is not None:
+            _ck(lib.semseg_wino_filter_transform(_p(w_oihw), _p(self.U_dgrad), self.Co, self.Ci, self.Ci_pad, self.Kc, 1,
+                                                 _stream()), "wino_filter_transform")
+
+
+def wino_tiles(N, H, W, dil):
+    t = int(lib.semseg_wino_tiles(N, H, W, dil))
+    if t < 0:
+        raise HipError("wino_tiles: bad geometry")
+    return t
+
+
+def wino_input_transform(src, lds, V, N, H, W, C, dil):
+    _ck(lib.semseg_wino_input_transform(_p(src), lds, _p(V), N, H, W, C, dil, _stream()), "wino_input_transform")
+
+
+def wino_dy_transform_wgrad(dy, lddy, Yh, ldo, N, H, W, C, dil):
+    _ck(lib.semseg_wino_dy_transform_wgrad(_p(dy), lddy, _p(Yh), ldo, N, H, W, C, dil, _stream()),
+        "wino_dy_transform_wgrad")
+
+
+def wino_output_transform(M, ldm, y, ldy, N, H, W, C, dil, add=None, ldadd=0, stats=None, nslot=1):
+    _ck(lib.semseg_wino_output_transform(_p(M), ldm, _p(y), ldy, _p(add), ldadd, _p(stats), nslot, N, H, W, C, dil,
+                                         _stream()), "wino_output_transform")
+
+
+def wino_filter_grad(dU, dw, Co, Ci, accumulate=False):
+    _ck(lib.semseg_wino_filter_grad(_p(dU), _p(dw), Co, Ci, int(accumulate), _stream()), "wino_filter_grad")
+
+
+def wino_conv_fwd(x, ldx, wc, y, ldy, N, H, W, dil, V, Mbuf, stats=None, nslot=1, add=None, ldadd=0):
+    """y[N,H,W,ldy] = conv3x3(x, w; stride 1, padding = dilation = dil).  V [16*T*Ci] receives the transformed input
+    (kept by the caller for the weight gradient), Mbuf [>= 16*T*Co] is scratch."""
+    T = wino_tiles(N, H, W, dil)
+    Ci, Co = wc.Ci, wc.Co
+    wino_input_transform(x, ldx, V, N, H, W, Ci, dil)
+    gemm_rows_batched(V, Ci, T * Ci, wc.U_fwd, wc.Co_pad * Ci, Mbuf, Co, T * Co, T, Ci, Co, 16)
+    wino_output_transform(Mbuf, Co, y, ldy, N, H, W, Co, dil, add=add, ldadd=ldadd, stats=stats, nslot=nslot)
+    return T
+
+
+def wino_conv_dgrad(dy, lddy, wc, dx, lddx, N, H, W, dil, Vdy, Mbuf, add=None, ldadd=0):
+    """dx[N,H,W,lddx] (= | + add) = the data gradient of the same convolution: a 3x3 convolution of dy with the
+    transposed filter, taps rotated by 180 degrees.  dy must be readable (zero) up to Kc = roundup(Co, 32) channels."""
+    T = wino_tiles(N, H, W, dil)
+    Ci, Kc = wc.Ci, wc.Kc
+    assert lddy >= Kc
+    wino_input_transform(dy, lddy, Vdy, N, H, W, Kc, dil)
+    gemm_rows_batched(Vdy, Kc, T * Kc, wc.U_dgrad, wc.Ci_pad * Kc, Mbuf, Ci, T * Ci, T, Kc, Ci, 16)
+    wino_output_transform(Mbuf, Ci, dx, lddx, N, H, W, Ci, dil, add=add, ldadd=ldadd)
+    return T
+
+
+def wino_conv_wgrad(V, dy, lddy, wc, dw, N, H, W, dil, Yh, dU, scratch, accumulate=False):
+    """dw[Co][Ci][3][3] from the kept transformed input V and dy.  Yh [16*T*roundup(Co,128)] zero-initialised scratch
+    (its padding columns must stay zero), dU [16*Co*Ci] scratch."""
+    T = wino_tiles(N, H, W, dil)
+    Ci, Co = wc.Ci, wc.Co
+    ldo = roundup(Co, 128)
+    wino_dy_transform_wgrad(dy, lddy, Yh, ldo, N, H, W, roundup(Co, 4), dil)
+    gemm_kmajor_batched(V, Ci, T * Ci, Yh, ldo, T * ldo, dU, Co * Ci, scratch, T, Ci, Co, 16)
+    wino_filter_grad(dU, dw, Co, Ci, accumulate)
+
+
 def wgrad_scratch_floats(Ci, Co, R, S):
     return int(lib.semseg_conv_wgrad_scratch_floats(Ci, Co, R, S))
 

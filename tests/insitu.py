@@ -28,6 +28,14 @@ import torch.nn.functional as F
 
 RATIO = 3.0
 RATIO_MAX = 5.0
+# Convs that run the Winograd F(2x2, 3x3) path (round 3): every output is recombined from 9 of the 16 element-wise
+# products with alternating signs, each about as large as the result, so the rounding noise of a sum of like-sized terms
+# is amplified by ~sqrt(9) = 3 over the direct convolution's (measured when the path was first run through this test:
+# rms 1.5 - 4.1 x the CPU-fp32 error on dgrad, 1.8 x on wgrad; relative rms error 7e-7).  Their bound is the direct
+# kernels' bound (which sits at 2.0 - 2.5 x for the worst direct layer) times that factor, rounded down: 6 x rms,
+# 10 x max-abs.  Quantities are reported as "dgrad-wino" / "wgrad-wino" so the two populations stay separate.
+RATIO_WINO = 6.0
+RATIO_MAX_WINO = 10.0
 FLOOR = 2e-7   # two fp32 ulps of the largest element: ops that are exact on the CPU (pure routing) have err_cpu = 0
 
 
@@ -111,7 +119,11 @@ class InsituChecker:
         self.rows.append((kind, name, qty, mh, mc, rh, rc))
 
     def failures(self):
-        return [r for r in self.rows if not (r[5] <= RATIO * r[6] + FLOOR and r[3] <= RATIO_MAX * r[4] + FLOOR)]
+        def ok(r):
+            wino = r[2].endswith("-wino")
+            kr, km = (RATIO_WINO, RATIO_MAX_WINO) if wino else (RATIO, RATIO_MAX)
+            return r[5] <= kr * r[6] + FLOOR and r[3] <= km * r[4] + FLOOR
+        return [r for r in self.rows if not ok(r)]
 
     def summary(self):
         by = {}
@@ -143,7 +155,8 @@ class InsituChecker:
         kw = dict(stride=cl.stride, padding=cl.pad, dilation=cl.dil)
         gw64, gx64 = conv_bwd_taps(xs, w.shape, w, dy, cl.stride, cl.pad, cl.dil, want_dx=has_dx)
         gw32 = torch.nn.grad.conv2d_weight(xs, w.shape, dy, **kw)
-        self._rec("conv", name, "wgrad", cl.wgrad.detach().cpu(), gw64, gw32)
+        wino = "-wino" if getattr(cl, "wino", None) is not None else ""
+        self._rec("conv", name, "wgrad" + wino, cl.wgrad.detach().cpu(), gw64, gw32)
         if m.bias is not None:
             self._rec("conv", name, "bgrad", cl.bgrad.detach().cpu(), dy.double().sum((0, 2, 3)), dy.sum((0, 2, 3)))
         if has_dx:
@@ -151,7 +164,7 @@ class InsituChecker:
             if gx0 is not None:
                 gx64 = gx64 + gx0.double()
                 gx32 = gx32 + gx0
-            qty = "dgrad"
+            qty = "dgrad" + wino
             if x.bn_reduced:
                 # this launch also did the BatchNorm-backward reduction of the layer that produced x: what it stored is
                 # g = dx * (x > 0); the sums it accumulated are checked by the BatchNorm entry (dgamma / dbeta / dy)

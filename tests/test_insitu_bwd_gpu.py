@@ -6,6 +6,7 @@ recomputed on the CPU in fp64 AND fp32 from the operands the HIP path itself use
 conditioning of the 100-layer network cannot hide (or fake) a kernel error.  Criterion for every dgrad, wgrad,
 BatchNorm-backward, upsample/pool adjoint, CE-backward and PSA adjoint:
     rms error: hip <= 3 x cpu_fp32 + 2e-7;   max-abs error: hip <= 5 x cpu_fp32 + 2e-7    (both vs the fp64 recompute)
+and 6 x / 10 x for the convolutions on the Winograd F(2x2, 3x3) path (tests/insitu.py: RATIO_WINO, with the reason).
 The train-mode losses of the same step are checked against the CPU oracle (oracle/segnet.py, pinned to the imported
 reference) at 1e-5, which also covers "PSPNet-101 473^2 train losses vs oracle".
 """
@@ -68,10 +69,12 @@ def test_insitu_psanet_variants(cfg, report):
 def test_insitu_pspnet101_473(report):
     """The metric model at the metric resolution (per-GPU batch 2)."""
     chk = _case(report, "pspnet101 c150 473^2 b2", "psp", 101, 150, 473, 2)
-    assert sum(1 for r in chk.rows if r[0] == "conv" and r[2] == "wgrad") == 113   # every MFMA conv of the net
-    # bn1 / bn2 of all 33 bottlenecks and the block outputs (except the one written into the concat buffer) have their
-    # BatchNorm-backward reduction folded into the data gradient that completes their gradient
-    assert sum(1 for r in chk.rows if r[2] == "dgrad+bnr") >= 90
+    assert sum(1 for r in chk.rows if r[0] == "conv" and r[2].startswith("wgrad")) == 113   # every MFMA conv of the net
+    # the 23 + 3 dilated conv2 of layer3 / layer4, the 3 stride-1 conv2 of layer2 and both head convs run the Winograd path
+    assert sum(1 for r in chk.rows if r[2] == "wgrad-wino") == 31
+    # bn1 of the direct-conv blocks, bn2 of all 33 bottlenecks and the block outputs (except the one written into the
+    # concat buffer) have their BatchNorm-backward reduction folded into the data gradient that completes their gradient
+    assert sum(1 for r in chk.rows if r[2] == "dgrad+bnr") >= 60
 
 
 @pytest.mark.skipif(os.environ.get("SEMSEG_SKIP_BIG_INSITU") == "1", reason="big in-situ cases disabled")

@@ -718,3 +718,65 @@ def test_conv_rounding_noise_vs_reduction_length(Ci, k, rows_n, report):
         errs.append(rms(nchw(yb).cpu().double()))
     report("conv noise K=%d: rms unsplit %.2e split-K %.2e torch-cpu-fp32 %.2e" % (Ci * k * k, errs[0], errs[1], e_cpu))
     assert errs[1] <= 3.0 * e_cpu + 1e-7 and errs[0] <= 4.0 * e_cpu + 1e-7
+
+
+WINO_CASES = [  # N, H, W, Ci, Co, dilation
+    (2, 12, 12, 64, 64, 1),
+    (1, 15, 13, 64, 96, 2),      # odd sizes: partial tiles in some phases
+    (2, 9, 11, 64, 128, 1),
+    (1, 17, 17, 128, 128, 4),    # dilation 4: 16 phases of 5 / 4 rows
+    (2, 30, 30, 256, 256, 2),    # layer3's conv2 at a small batch
+    (1, 8, 8, 512, 64, 1),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_conv_fwd_dgrad_wgrad(case, report):
+    """Winograd F(2x2, 3x3) path (input / filter / output transforms + the batched matrix-core GEMMs) against fp64
+    F.conv2d and its gradients: kernel 3, stride 1, padding = dilation; operands in wider buffers; statistics and the
+    accumulate-into-dx form included.  Same bound as the direct kernels."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co, d = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * (1.0 / (Ci * 9) ** 0.5)
+    dy = torch.randn(N, Co, H, W, generator=g)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, 1, d, d)
+    y64.backward(dy.double())
+    wc = ops.WinoConv(Co, Ci, DEV)
+    wc.transform(w.to(DEV))
+    T = ops.wino_tiles(N, H, W, d)
+    ldx, ldy = Ci + 32, ops.roundup(Co, 128) + 64
+    xb = torch.randn(N, H, W, ldx, device=DEV)
+    xb[..., 16:16 + Ci] = nhwc(x).to(DEV)
+    yb = torch.full((N, H, W, ldy), float("nan"), device=DEV)
+    V = torch.empty(16 * T * Ci, device=DEV)
+    Mbuf = torch.empty(16 * T * max(Ci, Co), device=DEV)
+    st = torch.zeros(ops.NSLOT * 2 * Co, dtype=torch.float64, device=DEV)
+    ops.wino_conv_fwd(xb[..., 16:], ldx, wc, yb, ldy, N, H, W, d, V, Mbuf, stats=st, nslot=ops.NSLOT)
+    y = yb[..., :Co].permute(0, 3, 1, 2)
+    e_f = relerr(y, y64.detach())
+    assert torch.isnan(yb[..., Co:]).all()                     # nothing written beyond the valid channels
+    s = st.view(ops.NSLOT, 2, Co).sum(0).cpu()
+    ref_s = torch.stack([y64.detach().sum((0, 2, 3)), (y64.detach() ** 2).sum((0, 2, 3))])
+    e_s = float((s - ref_s).abs().max() / ref_s.abs().max())
+    # data gradient, accumulated onto an existing gradient
+    dyb = torch.zeros(N, H, W, ldy, device=DEV)
+    dyb[..., :Co] = nhwc(dy).to(DEV)
+    base = torch.randn(N, H, W, ldx, device=DEV)
+    dxb = base.clone()
+    Vdy = torch.empty(16 * T * wc.Kc, device=DEV)
+    ops.wino_conv_dgrad(dyb, ldy, wc, dxb[..., 16:], ldx, N, H, W, d, Vdy, Mbuf, add=base[..., 16:], ldadd=ldx)
+    dx = (dxb[..., 16:16 + Ci] - base[..., 16:16 + Ci]).permute(0, 3, 1, 2)
+    e_d = relerr(dx, x64.grad)
+    assert torch.equal(dxb[..., :16], base[..., :16]) and torch.equal(dxb[..., 16 + Ci:], base[..., 16 + Ci:])
+    # weight gradient from the kept transformed input
+    Yh = torch.zeros(16 * T * ops.roundup(Co, 128), device=DEV)
+    dU = torch.empty(16 * Co * Ci, device=DEV)
+    scratch = torch.empty(16 * 1024 * 1024, device=DEV)
+    dw = torch.full((Co, Ci, 3, 3), float("nan"), device=DEV)
+    ops.wino_conv_wgrad(V, dyb, ldy, wc, dw, N, H, W, d, Yh, dU, scratch)
+    e_w = relerr(dw, w64.grad)
+    report("winograd %s: fwd %.2e stats %.2e dgrad %.2e wgrad %.2e" % (case, e_f, e_s, e_d, e_w))
+    assert e_f < 2e-5 and e_d < 2e-5 and e_w < 2e-5 and e_s < 1e-5
