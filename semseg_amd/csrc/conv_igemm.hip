@@ -1537,7 +1537,9 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   // (scripts/conv_bench.py 2|4|8): 1x1 with 16 tiles -18 % at M = 7200, -12 % at 14400, -4 % at 28800;
   // 3x3 with 36 tiles -9 % at 7200, +2 % at 14400; cls.0 (1152 tiles) +10...18 % everywhere.
   const int t128 = ((Co + 127) / 128) * (Ci / 128) * RS;
-  const bool small_tiles = (RS == 1 && t128 <= 16 && M < 32768) || (RS > 1 && t128 <= 36 && M < 8192);
+  // (a batched launch multiplies the grid by the batch: the 16 GEMMs of a Winograd weight gradient fill the chip with
+  // 128 x 128 tiles where a single GEMM of that size would not)
+  const bool small_tiles = batch == 1 && ((RS == 1 && t128 <= 16 && M < 32768) || (RS > 1 && t128 <= 36 && M < 8192));
   const char* small_s = getenv("SEMSEG_WGRAD_SMALL");   // "0": never fall back to 64 x 64 tiles (tests / tuning)
   const bool allow_small = !(small_s && small_s[0] == '0');
   const bool big = (Ci % 128 == 0) && (Co >= 128) && !(allow_small && small_tiles);
