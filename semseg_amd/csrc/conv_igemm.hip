@@ -114,7 +114,8 @@ __device__ __forceinline__ void decode_tile(const ConvArgs& p, int tile, int& ti
 // ---- epilogue shared by the register-staged and the direct-to-LDS kernels ----
 template <int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2][BN / 64], float* smem, bool split,
-                                              int ks, int m0, int n0, int tile_m, double* red2) {
+                                              int ks, int m0, int n0, int tile_m, double* red2, float* y_out,
+                                              const float* add_in) {
   constexpr int NT = BM * 2;
   constexpr int MREP = 2, NREP = BN / 64;
   const int tid = threadIdx.x;
@@ -127,11 +128,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
   // slab and stores 16-byte lanes (8 per block instead of 32); bias / residual add ride along.
   // Statistics are taken from the accumulators (+bias) in registers, in fp64.
   const int Nout4 = (p.Nout + 3) & ~3;
-  float* const dst = split ? p.part + (size_t)ks * (p.M - p.tail_m0) * p.ldpart : p.y;
+  float* const dst = split ? p.part + (size_t)ks * (p.M - p.tail_m0) * p.ldpart : y_out;
   const int ldd = split ? p.ldpart : p.ldy;
   const int mrow0 = split ? p.tail_m0 : 0;           // partial slabs start at the tail's first row
   const int colmax = split ? p.ldpart : Nout4;       // widest column a 16-byte store may touch
-  const bool wide = split || ((p.ldy & 3) == 0 && p.ldy >= Nout4 && (!p.add || (p.ldadd & 3) == 0));
+  const bool wide = split || ((p.ldy & 3) == 0 && p.ldy >= Nout4 && (!add_in || (p.ldadd & 3) == 0));
   float* wl = smem + wave * (64 * LDK);              // this wave's slab (needs >= NT/64 * 64 * LDK floats)
   double* red = reinterpret_cast<double*>(smem);     // [BM/64 (wm)][BN][2], used after the stores
   const bool bnr = !split && p.bnr_n > 0;            // fused BatchNorm-backward reduction (wide stores only)
@@ -184,8 +185,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
         // kernel from 159 to 223 VGPRs (residency 3 -> 2, and no room beside the weight-gradient workgroups).
         // Out-of-range rows / columns load from a clamped address and are dropped at the store; absent operands (no
         // residual add, no second BatchNorm, no ReLU mask) alias a present one and are neutralised arithmetically.
-        const bool has_add = p.add != nullptr, has_mask = p.bnr_mask != nullptr, two = p.bnr_n > 1;
-        const float* addp = has_add ? p.add : p.bnr_y[0];
+        const bool has_add = add_in != nullptr, has_mask = p.bnr_mask != nullptr, two = p.bnr_n > 1;
+        const float* addp = has_add ? add_in : p.bnr_y[0];
         const int ldap = has_add ? p.ldadd : p.bnr_ldy[0];
         const float addw = has_add ? 1.f : 0.f;
         const float* maskp = has_mask ? p.bnr_mask : p.bnr_y[0];
@@ -229,7 +230,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
         const int cg = n0 + wn * (BN / 2) + j * 32 + c4;
         f32x4 v = *reinterpret_cast<const f32x4*>(&wl[lr * LDK + c4]);
         if (m < p.M && cg < colmax) {
-          if (!split && p.add) v += *reinterpret_cast<const f32x4*>(p.add + (size_t)m * p.ldadd + cg);
+          if (!split && add_in) v += *reinterpret_cast<const f32x4*>(add_in + (size_t)m * p.ldadd + cg);
           if (relu) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -264,9 +265,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
             const double dv = (double)v;
             s1 += dv;
             s2 += dv * dv;
-            if (p.add) v += p.add[(size_t)m * p.ldadd + col];
+            if (add_in) v += add_in[(size_t)m * p.ldadd + col];
             if (relu) v = fmaxf(v, 0.f);
-            p.y[(size_t)m * p.ldy + col] = v;
+            y_out[(size_t)m * p.ldy + col] = v;
           }
         }
     }
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
         for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
   }
 
-  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m, reinterpret_cast<double*>(smem + SMEM_BASE));
+  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m, reinterpret_cast<double*>(smem + SMEM_BASE), p.y, p.add);
 }
 
 // Split-K epilogue: y = sum_ks part[ks] (+bias) (+add); optional fp64 channel statistics.
