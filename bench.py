@@ -314,6 +314,7 @@ def main():
         torch.cuda.synchronize()
         for e, sw, hp in saved:
             e.side_wgrad, e.hipri_main, e.ktimer = sw, hp, None
+    exec_flops = kt_iso.mfma_flops() / ISO_STEPS if kt_iso is not None else None
     kfam = kt_iso.summary() if kt_iso is not None else None
     kfam_in = kt.summary() if kt is not None else None
     roof = None
@@ -359,10 +360,17 @@ def main():
                                 "nn.Module drop-in + torch.optim.SGD (tool/train.py:269-276 unchanged)"),
                        "tile_table": _tile_summary()},
             "final_main_loss": round(loss_val, 5),
+            # direct-convolution FLOPs of the step (SURVEY.md section 8d / BASELINE.md section 4: 3 x forward - first conv's
+            # data gradient) — the work the metric is defined on; the stride-1 3x3 convs with >= 128 channels EXECUTE
+            # 1 / 2.25 of their share (Winograd F(2x2,3x3), fp32), so this rate can exceed what the matrix cores ran
             "algorithmic_tflop_per_step": round(step_flops / 1e12, 3),
-            "whole_step_frac_of_f32_mfma_peak": round(step_flops / (dt / args.steps) / 1e12 / world /
-                                                      PEAK_F32_MFMA_TFLOPS, 4),
+            "algorithmic_tflops_over_f32_mfma_peak": round(step_flops / (dt / args.steps) / 1e12 / world /
+                                                           PEAK_F32_MFMA_TFLOPS, 4),
         }
+        if exec_flops is not None:
+            out["executed_mfma_tflop_per_step"] = round(exec_flops * world / 1e12, 3)
+            out["whole_step_frac_of_f32_mfma_peak"] = round(exec_flops / (dt / args.steps) / 1e12 /
+                                                            PEAK_F32_MFMA_TFLOPS, 4)
         other = sec_module if primary_trainer else sec_trainer
         if other is not None:
             out["module_path" if primary_trainer else "trainer_path"] = {

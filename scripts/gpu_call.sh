@@ -1,3 +1,9 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "conv or gemm or winograd or psa" 2>&1 | tail -3
-for pz in 0 1; do echo "== SEMSEG_GEMM_PERSIST=$pz"; SEMSEG_GEMM_PERSIST=$pz python scripts/conv_bench.py 2>&1 | grep "1x1\|weighted"; SEMSEG_GEMM_PERSIST=$pz python scripts/wino_bench.py 16 2>&1 | grep "l3 conv2\|l4 conv2\|aux.0\|cls.0\|per step"; done
+timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03_bench5.json 2> gpurun_out/r03_bench5.err; echo "bench rc $?"; tail -3 gpurun_out/r03_bench5.err
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r03_bench5.json").read().strip().splitlines()[-1])
+print({k:v for k,v in d.items() if k not in ("kernel_families","kernel_families_in_step","config","roofline")})
+print(d["roofline"])
+for k,v in d["kernel_families"].items(): print(k,v)
+PY

@@ -31,6 +31,8 @@ class KernelTimer:
         self.rec = []
 
     def span(self, family, flops):
+        """flops > 0: matrix-core work (algorithmic FLOPs executed by the launch); flops < 0: an HBM-bound kernel,
+        -flops = algorithmic bytes it moves."""
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.rec.append((family, flops, s, e))
         return s, e
@@ -48,12 +50,20 @@ class KernelTimer:
     def summary(self):
         out = {}
         for k, (n, fl, t) in sorted(self._collect().items(), key=lambda kv: -kv[1][2]):
-            out[k] = {"launches": n, "total_ms": round(t * 1e3, 3), "avg_us": round(t / n * 1e6, 2),
-                      "tflops": round(fl / t / 1e12, 2) if t > 0 else None}
+            out[k] = {"launches": n, "total_ms": round(t * 1e3, 3), "avg_us": round(t / n * 1e6, 2)}
+            if fl >= 0:
+                out[k]["tflops"] = round(fl / t / 1e12, 2) if t > 0 else None
+            else:
+                out[k]["hbm_tb_per_s_algorithmic"] = round(-fl / t / 1e12, 2) if t > 0 else None
         return out
+
+    def mfma_flops(self):
+        """FLOPs executed on the matrix cores over everything recorded (Winograd GEMMs count what they execute)."""
+        return sum(fl for _, fl, _, _ in self.rec if fl > 0)
 
     def roofline(self, peak_tflops, family=None):
         fam = self._collect()
+        fam = {k: v for k, v in fam.items() if v[1] > 0}      # matrix-core families only
         if family is not None:
             k, (n, fl, t) = family, fam[family]
         else:
@@ -100,6 +110,7 @@ class Act:
         return a
 
 
+WINO_HBM = "wino_input / wino_output / wino_dy_wgrad / wino_filter_grad kernels (Winograd transforms, HBM-bound)"
 WINOGRAD = os.environ.get("SEMSEG_WINOGRAD", "1") != "0"   # 0: every 3x3 conv on the direct implicit-GEMM kernels (A/B)
 
 
@@ -392,11 +403,8 @@ class Engine:
             assert fold is None and not bias and self.training
             T = ops.wino_tiles(x.N, x.H, x.W, cl.dil)
             V = self.buf((16 * T * cl.Ci,), tag="winoV")      # kept: the weight gradient contracts it with dy
-            ev = self._t0("winograd F(2x2,3x3) fwd: transforms + batched conv_igemm_kernel<128,128,false,1>",
-                          2.0 * 16 * T * cl.Co * cl.Ci)
-            ops.wino_conv_fwd(x.data, x.ld, cl.wino, out.data, out.ld, x.N, x.H, x.W, cl.dil, V,
-                              self._wino_scratch("M", 16 * T * max(cl.Ci, cl.Co)), stats=stats, nslot=ops.NSLOT)
-            self._t1(ev)
+            self._wino_rows(x.data, x.ld, cl.Ci, cl.wino.U_fwd, cl.wino.Co_pad, out.data, out.ld, cl.Co, x.N, x.H, x.W,
+                            cl.dil, T, V, stats=stats)
             if x.fuse_ok:
                 x.pending += 1
             self.push("conv", lambda: self._conv_bwd_wino(x, out, cl, m, V, T), x=x, y=out, cl=cl, m=m)
@@ -494,6 +502,23 @@ class Engine:
             t = _SHARED[key] = (torch.zeros if name == "Yh" else torch.empty)(floats, dtype=F32, device=self.device)
         return t
 
+    def _wino_rows(self, src, lds, K, U, rows_pad, dst, ldd, Nout, N, H, W, d, T, V, stats=None, add=None, ldadd=0):
+        """input transform -> 16 batched row GEMMs [T x K] x [K x Nout] -> output transform: the forward of a Winograd conv
+        (src = x, U = U_fwd) and its data gradient (src = dy, U = the flipped / transposed filter)."""
+        px = N * H * W
+        Mb = self._wino_scratch("M", 16 * T * Nout)
+        ev = self._t0(WINO_HBM, -4.0 * (px * K + 16 * T * K))
+        ops.wino_input_transform(src, lds, V, N, H, W, K, d)
+        self._t1(ev)
+        ev = self._t0("conv_igemm_kernel<128,%d,false,1>(+splitk_epilogue)" % (128 if Nout >= 128 else 64),
+                      2.0 * 16 * T * Nout * K)
+        ops.gemm_rows_batched(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16)
+        self._t1(ev)
+        ev = self._t0(WINO_HBM, -4.0 * (16 * T * Nout + px * Nout * (2 if add is not None else 1)))
+        ops.wino_output_transform(Mb, Nout, dst, ldd, N, H, W, Nout, d, add=add, ldadd=ldadd, stats=stats,
+                                  nslot=ops.NSLOT)
+        self._t1(ev)
+
     def _conv_bwd_wino(self, x, y, cl, m, V, T):
         """Backward of a Winograd conv: weight gradient dU[e] = Yh[e]^T V[e] on the side stream (one batched K-major GEMM,
         V kept from forward), data gradient = the forward machinery on dy with the flipped filter on the main chain."""
@@ -503,9 +528,16 @@ class Engine:
         gflops = 2.0 * 16 * T * cl.Co * cl.Ci
 
         def wgrad(scr):
-            ev = self._t0("winograd F(2x2,3x3) wgrad: transforms + batched conv_wgrad_dma_kernel<128x128>+reduce", gflops)
-            ops.wino_conv_wgrad(V, dy, y.ld, cl.wino, cl.wgrad, N, H, W, d,
-                                self._wino_scratch("Yh", 16 * T * cl.Co), self._wino_scratch("dU", 16 * cl.Co * cl.Ci), scr)
+            Yh, dU = self._wino_scratch("Yh", 16 * T * cl.Co), self._wino_scratch("dU", 16 * cl.Co * cl.Ci)
+            px = N * H * W
+            ev = self._t0(WINO_HBM, -4.0 * (px * cl.Co + 16 * T * cl.Co))
+            ops.wino_dy_transform_wgrad(dy, y.ld, Yh, cl.Co, N, H, W, cl.Co, d)
+            self._t1(ev)
+            ev = self._t0("conv_wgrad_dma_kernel<128x128>+reduce", gflops)
+            ops.gemm_kmajor_batched(V, cl.Ci, T * cl.Ci, Yh, cl.Co, T * cl.Co, dU, cl.Co * cl.Ci, scr, T, cl.Ci, cl.Co, 16)
+            self._t1(ev)
+            ev = self._t0(WINO_HBM, -4.0 * 25 * cl.Co * cl.Ci)
+            ops.wino_filter_grad(dU, cl.wgrad, cl.Co, cl.Ci)
             self._t1(ev)
             self._ready([m.weight])
 
@@ -521,11 +553,8 @@ class Engine:
             gx = self.grad_of(x)
             if x.fuse_ok:
                 x.pending -= 1      # no fused BatchNorm-backward reduction on this path: _bn_act_bwd runs its own pass
-            ev = self._t0("winograd F(2x2,3x3) dgrad: transforms + batched conv_igemm_kernel<128,128,false,1>", gflops)
-            ops.wino_conv_dgrad(dy, y.ld, cl.wino, gx, x.ld, N, H, W, d, self._wino_scratch("Vdy", 16 * T * cl.wino.Kc),
-                                self._wino_scratch("M", 16 * T * max(cl.Ci, cl.Co)),
-                                add=gx if x.ginit else None, ldadd=x.ld)
-            self._t1(ev)
+            self._wino_rows(dy, y.ld, cl.wino.Kc, cl.wino.U_dgrad, cl.wino.Ci_pad, gx, x.ld, cl.Ci, N, H, W, d, T,
+                            self._wino_scratch("Vdy", 16 * T * cl.wino.Kc), add=gx if x.ginit else None, ldadd=x.ld)
             x.ginit = True
 
     def _side_stream(self):
