@@ -111,6 +111,13 @@ int semseg_wino_dy_transform_wgrad(const float* dy, int lddy, float* Yh, int ldo
 /* y = A^T M A (+ add); stats (optional, [nslot][2*C] fp64, caller-zeroed) += {sum y, sum y^2} of the values before add */
 int semseg_wino_output_transform(const float* M, int ldm, float* y, int ldy, const float* add, int ldadd, double* stats,
                                  int nslot, int N, int H, int W, int C, int dil, hipStream_t stream);
+/* The output transform of a DATA GRADIENT that completes the gradient of a BatchNorm(+ReLU) output, with that layer's
+ * BatchNorm-backward reduction folded in (contract of semseg_conv_dgrad_bnreduce, one BatchNorm layer): stores
+ * g = (A^T M A + add) * (act > 0) and accumulates sums[slot][2*C] += {sum g, sum g * (ybn - mean) * invstd} in fp64. */
+int semseg_wino_output_transform_bnreduce(const float* M, int ldm, float* y, int ldy, const float* add, int ldadd,
+                                          const float* act, int ldact, const float* ybn, int ldybn, const float* mean,
+                                          const float* invstd, double* sums, int nslot, int N, int H, int W, int C,
+                                          int dil, hipStream_t stream);
 /* flip 0: U[e][co][ci] (rows_pad >= Co, Kc >= Ci);  flip 1: U[e][ci][co] with taps rotated 180 degrees (rows_pad >= Ci,
  * Kc >= Co); padding rows / columns are written as zero */
 int semseg_wino_filter_transform(const float* w_oihw, float* U, int Co, int Ci, int rows_pad, int Kc, int flip,

@@ -149,6 +149,15 @@ struct WinoOutArgs {
   double* stats;
   int ldm, ldy, ldadd, C, nslot;
   WinoGeo g;
+  // Fused BatchNorm-backward reduction (data gradient of a conv whose input is a BatchNorm(+ReLU) output and whose
+  // gradient this launch completes; same contract as semseg_conv_dgrad_bnreduce): what is stored is
+  // g = (Y + add) * (act > 0), and stats += {sum g, sum g * (ybn - mean) * invstd}.  bnr == 0: off.
+  int bnr;
+  const float* act;      // post-ReLU activation (nullptr: no ReLU)
+  const float* ybn;      // pre-BatchNorm tensor
+  const float* mean;
+  const float* invstd;
+  int ldact, ldybn;
 };
 
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs p) {
@@ -164,6 +173,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs p) {
   const int c = c4 * 4;
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const WinoGeo g = p.g;
+  f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bis = {0.f, 0.f, 0.f, 0.f};
+  if (active && p.bnr) {
+    bmu = *reinterpret_cast<const f32x4*>(p.mean + c);
+    bis = *reinterpret_cast<const f32x4*>(p.invstd + c);
+  }
   if (active) {
     const size_t plane = (size_t)g.T * p.ldm;
     for (int t = blockIdx.y * rpb + tr; t < g.T; t += gridDim.y * rpb) {
@@ -192,6 +206,22 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs p) {
           if (x >= g.W) continue;
           f32x4 v = b == 0 ? o0 : o1;
           const size_t pix = (size_t)(n * g.H + y) * g.W + x;
+          if (p.bnr) {
+            if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + pix * p.ldadd + c);
+            if (p.act) {
+              const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.act + pix * p.ldact + c);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = a4[k] > 0.f ? v[k] : 0.f;
+            }
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(p.ybn + pix * p.ldybn + c) - bmu) * bis;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              acc[k] += (double)v[k];
+              acc[4 + k] += (double)v[k] * (double)xh[k];
+            }
+            *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + c) = v;
+            continue;
+          }
           if (p.stats) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -299,6 +329,8 @@ __global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float* __re
   }
 }
 
+int launch_output(const WinoOutArgs& a, hipStream_t stream);
+
 inline int grid_1d(long long total) {
   long long g = (total + 255) / 256;
   if (g > 65535 * 16) g = 65535 * 16;
@@ -342,6 +374,30 @@ int semseg_wino_output_transform(const float* M, int ldm, float* y, int ldy, con
   a.M = M; a.y = y; a.add = add; a.stats = stats; a.ldm = ldm; a.ldy = ldy; a.ldadd = ldadd; a.C = C;
   a.nslot = nslot > 0 ? nslot : 1;
   a.g = make_geo(N, H, W, dil);
+  a.bnr = 0; a.act = nullptr; a.ybn = nullptr; a.mean = nullptr; a.invstd = nullptr; a.ldact = 0; a.ldybn = 0;
+  return launch_output(a, stream);
+}
+
+int semseg_wino_output_transform_bnreduce(const float* M, int ldm, float* y, int ldy, const float* add, int ldadd,
+                                          const float* act, int ldact, const float* ybn, int ldybn, const float* mean,
+                                          const float* invstd, double* sums, int nslot, int N, int H, int W, int C,
+                                          int dil, hipStream_t stream) {
+  if (!M || !y || !ybn || !mean || !invstd || !sums || nslot < 1 || (C & 3) || (ldm & 3) || (ldy & 3) || ldm < C ||
+      ldy < C || (add && (ldadd & 3)) || (act && (ldact & 3)) || (ldybn & 3) || semseg_wino_tiles(N, H, W, dil) < 0)
+    return SEMSEG_EINVAL;
+  WinoOutArgs a;
+  a.M = M; a.y = y; a.add = add; a.stats = sums; a.ldm = ldm; a.ldy = ldy; a.ldadd = ldadd; a.C = C; a.nslot = nslot;
+  a.g = make_geo(N, H, W, dil);
+  a.bnr = 1; a.act = act; a.ybn = ybn; a.mean = mean; a.invstd = invstd; a.ldact = ldact; a.ldybn = ldybn;
+  return launch_output(a, stream);
+}
+
+}  // extern "C"
+
+namespace {
+int launch_output(const WinoOutArgs& a, hipStream_t stream) {
+  const int C = a.C;
+  const double* stats = a.stats;
   const int C4 = C >> 2;
   int tpr = 1;
   while (tpr * 2 <= C4 && tpr * 2 <= 256) tpr *= 2;
@@ -355,6 +411,9 @@ int semseg_wino_output_transform(const float* M, int ldm, float* y, int ldy, con
   wino_output_kernel<<<dim3(gx, gy), 256, 0, stream>>>(a);
   return semseg_launch_status();
 }
+}  // namespace
+
+extern "C" {
 
 int semseg_wino_filter_transform(const float* w_oihw, float* U, int Co, int Ci, int rows_pad, int Kc, int flip,
                                  hipStream_t stream) {

@@ -502,7 +502,8 @@ class Engine:
             t = _SHARED[key] = (torch.zeros if name == "Yh" else torch.empty)(floats, dtype=F32, device=self.device)
         return t
 
-    def _wino_rows(self, src, lds, K, U, rows_pad, dst, ldd, Nout, N, H, W, d, T, V, stats=None, add=None, ldadd=0):
+    def _wino_rows(self, src, lds, K, U, rows_pad, dst, ldd, Nout, N, H, W, d, T, V, stats=None, add=None, ldadd=0,
+                   bnr=None):
         """input transform -> 16 batched row GEMMs [T x K] x [K x Nout] -> output transform: the forward of a Winograd conv
         (src = x, U = U_fwd) and its data gradient (src = dy, U = the flipped / transposed filter)."""
         px = N * H * W
@@ -514,9 +515,14 @@ class Engine:
                       2.0 * 16 * T * Nout * K)
         ops.gemm_rows_batched(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16)
         self._t1(ev)
-        ev = self._t0(WINO_HBM, -4.0 * (16 * T * Nout + px * Nout * (2 if add is not None else 1)))
-        ops.wino_output_transform(Mb, Nout, dst, ldd, N, H, W, Nout, d, add=add, ldadd=ldadd, stats=stats,
-                                  nslot=ops.NSLOT)
+        ev = self._t0(WINO_HBM, -4.0 * (16 * T * Nout + px * Nout * (1 + (add is not None) + (2 if bnr else 0))))
+        if bnr is not None:
+            act, ldact, ybn, ldybn, mean, invstd, sums = bnr
+            ops.wino_output_transform_bnreduce(Mb, Nout, dst, ldd, N, H, W, Nout, d, act, ldact, ybn, ldybn, mean,
+                                               invstd, sums, ops.NSLOT, add=add, ldadd=ldadd)
+        else:
+            ops.wino_output_transform(Mb, Nout, dst, ldd, N, H, W, Nout, d, add=add, ldadd=ldadd, stats=stats,
+                                      nslot=ops.NSLOT)
         self._t1(ev)
 
     def _conv_bwd_wino(self, x, y, cl, m, V, T):
@@ -551,10 +557,22 @@ class Engine:
             wgrad(self.scratch())
         if x.name != "input":
             gx = self.grad_of(x)
+            # as in _conv_bwd: when this data gradient completes x.grad and x is the output of ONE BatchNorm(+ReLU) whose
+            # consumers are all convs / residual adds, that layer's backward reduction rides in the output transform
+            last = x.fuse_ok and x.pending == 1
             if x.fuse_ok:
-                x.pending -= 1      # no fused BatchNorm-backward reduction on this path: _bn_act_bwd runs its own pass
+                x.pending -= 1
+            bs = x.bnsrc
+            bnr = None
+            if (self.fuse_bnr and last and bs is not None and len(bs["bns"]) == 1 and x.C % 4 == 0 and x.ld % 4 == 0
+                    and bs["bns"][0][0].ld % 4 == 0):
+                yk, blk = bs["bns"][0]
+                bnr = (x.data if bs["relu"] else None, x.ld, yk.data, yk.ld, blk.mean, blk.invstd, blk.sums)
             self._wino_rows(dy, y.ld, cl.wino.Kc, cl.wino.U_dgrad, cl.wino.Ci_pad, gx, x.ld, cl.Ci, N, H, W, d, T,
-                            self._wino_scratch("Vdy", 16 * T * cl.wino.Kc), add=gx if x.ginit else None, ldadd=x.ld)
+                            self._wino_scratch("Vdy", 16 * T * cl.wino.Kc), add=gx if x.ginit else None, ldadd=x.ld,
+                            bnr=bnr)
+            if bnr is not None:
+                x.bn_reduced = True
             x.ginit = True
 
     def _side_stream(self):

@@ -246,6 +246,13 @@ def wino_output_transform(M, ldm, y, ldy, N, H, W, C, dil, add=None, ldadd=0, st
                                          _stream()), "wino_output_transform")
 
 
+def wino_output_transform_bnreduce(M, ldm, y, ldy, N, H, W, C, dil, act, ldact, ybn, ldybn, mean, invstd, sums, nslot,
+                                   add=None, ldadd=0):
+    _ck(lib.semseg_wino_output_transform_bnreduce(_p(M), ldm, _p(y), ldy, _p(add), ldadd, _p(act), ldact, _p(ybn), ldybn,
+                                                  _p(mean), _p(invstd), _p(sums), nslot, N, H, W, C, dil, _stream()),
+        "wino_output_transform_bnreduce")
+
+
 def wino_filter_grad(dU, dw, Co, Ci, accumulate=False):
     _ck(lib.semseg_wino_filter_grad(_p(dU), _p(dw), Co, Ci, int(accumulate), _stream()), "wino_filter_grad")
 

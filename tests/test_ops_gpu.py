@@ -771,6 +771,23 @@ def test_winograd_conv_fwd_dgrad_wgrad(case, report):
     dx = (dxb[..., 16:16 + Ci] - base[..., 16:16 + Ci]).permute(0, 3, 1, 2)
     e_d = relerr(dx, x64.grad)
     assert torch.equal(dxb[..., :16], base[..., :16]) and torch.equal(dxb[..., 16 + Ci:], base[..., 16 + Ci:])
+    # the same data gradient with the BatchNorm-backward reduction of the layer that produced x folded into the output
+    # transform: g = (dx + add) * (act > 0), sums = {sum g, sum g * xhat}
+    act = torch.randn(N, H, W, ldx, device=DEV)
+    ybn = torch.randn(N, H, W, Ci + 4, device=DEV)
+    mean, invstd = torch.randn(Ci, device=DEV), torch.rand(Ci, device=DEV) + 0.5
+    sums = torch.zeros(ops.NSLOT * 2 * Ci, dtype=torch.float64, device=DEV)
+    gb = torch.full((N, H, W, ldx), float("nan"), device=DEV)
+    ops.wino_input_transform(dyb, ldy, Vdy, N, H, W, wc.Kc, d)
+    ops.gemm_rows_batched(Vdy, wc.Kc, T * wc.Kc, wc.U_dgrad, wc.Ci_pad * wc.Kc, Mbuf, Ci, T * Ci, T, wc.Kc, Ci, 16)
+    ops.wino_output_transform_bnreduce(Mbuf, Ci, gb[..., 16:], ldx, N, H, W, Ci, d, act[..., 16:], ldx, ybn, Ci + 4, mean,
+                                       invstd, sums, ops.NSLOT, add=base[..., 16:], ldadd=ldx)
+    g_ref = (nhwc(x64.grad) + base[..., 16:16 + Ci].double().cpu()) * (act[..., 16:16 + Ci] > 0).cpu()
+    xh = (ybn[..., :Ci].double().cpu() - mean.double().cpu()) * invstd.double().cpu()
+    s_ref = torch.stack([g_ref.sum((0, 1, 2)), (g_ref * xh).sum((0, 1, 2))])
+    e_g = relerr(gb[..., 16:16 + Ci], g_ref)
+    e_gs = float((sums.view(ops.NSLOT, 2, Ci).sum(0).cpu() - s_ref).abs().max() / s_ref.abs().max())
+    assert e_g < 2e-5 and e_gs < 1e-5, (e_g, e_gs)
     # weight gradient from the kept transformed input
     Yh = torch.zeros(16 * T * ops.roundup(Co, 128), device=DEV)
     dU = torch.empty(16 * Co * Ci, device=DEV)
