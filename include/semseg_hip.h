@@ -108,9 +108,12 @@ int semseg_wino_input_transform(const float* src, int lds, float* V, int N, int 
                                 hipStream_t stream);
 int semseg_wino_dy_transform_wgrad(const float* dy, int lddy, float* Yh, int ldo, int N, int H, int W, int C, int dil,
                                    hipStream_t stream);
-/* y = A^T M A (+ add); stats (optional, [nslot][2*C] fp64, caller-zeroed) += {sum y, sum y^2} of the values before add */
+/* y = [relu]((A^T M A) * scale + shift + add); scale / shift optional per-channel vectors (eval-mode BatchNorm folded in,
+ * as in semseg_conv_fwd); stats (optional, [nslot][2*C] fp64, caller-zeroed) += {sum, sum of squares} of the values
+ * before add */
 int semseg_wino_output_transform(const float* M, int ldm, float* y, int ldy, const float* add, int ldadd, double* stats,
-                                 int nslot, int N, int H, int W, int C, int dil, hipStream_t stream);
+                                 int nslot, const float* scale, const float* shift, int relu, int N, int H, int W, int C,
+                                 int dil, hipStream_t stream);
 /* The output transform of a DATA GRADIENT that completes the gradient of a BatchNorm(+ReLU) output, with that layer's
  * BatchNorm-backward reduction folded in (contract of semseg_conv_dgrad_bnreduce, one BatchNorm layer): stores
  * g = (A^T M A + add) * (act > 0) and accumulates sums[slot][2*C] += {sum g, sum g * (ybn - mean) * invstd} in fp64. */

@@ -1,3 +1,2 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-SEMSEG_RUN_COMPARATOR=1 COMPARATOR_FIND=0 timeout 330 python -m pytest tests/test_comparator_gpu.py -m gpu -q -s 2>&1 | tail -5
-grep -i "comparator" gpurun_out/parity_report.txt | tail -2
+timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/r03_pytest_full.log 2>&1; grep -E "passed|failed" gpurun_out/r03_pytest_full.log | tail -3; grep -E "^FAILED|^ERROR" gpurun_out/r03_pytest_full.log | head

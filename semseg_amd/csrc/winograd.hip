@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void wino_dy_wgrad_kernel(const float* __restr
 }
 
 // Y = A^T M A (2x2 from 4x4), A^T = [1 1 1 0; 0 1 -1 -1].  M[16][T][ldm] -> y NHWC [N][H][W][ldy] (+ add), optional fp64
-// per-channel statistics [nslot][2C] of the stored values (before add), as the conv epilogue produces them.
+// per-channel statistics [nslot][2C] of the stored values (before add), as the conv epilogue produces them; optional
+// per-channel scale / shift and ReLU (the eval-mode BatchNorm + ReLU + residual epilogue of the direct kernel).
 struct WinoOutArgs {
   const float* M;
   float* y;
@@ -152,6 +153,10 @@ struct WinoOutArgs {
   // Fused BatchNorm-backward reduction (data gradient of a conv whose input is a BatchNorm(+ReLU) output and whose
   // gradient this launch completes; same contract as semseg_conv_dgrad_bnreduce): what is stored is
   // g = (Y + add) * (act > 0), and stats += {sum g, sum g * (ybn - mean) * invstd}.  bnr == 0: off.
+  // eval-mode epilogue (BatchNorm with running statistics, ReLU, residual folded in): y = [relu](Y * scale + shift + add)
+  const float* scale;
+  const float* shift;
+  int relu;
   int bnr;
   const float* act;      // post-ReLU activation (nullptr: no ReLU)
   const float* ybn;      // pre-BatchNorm tensor
@@ -174,6 +179,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs p) {
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const WinoGeo g = p.g;
   f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bis = {0.f, 0.f, 0.f, 0.f};
+  f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
+  if (active && p.scale) esc = *reinterpret_cast<const f32x4*>(p.scale + c);
+  if (active && p.shift) esh = *reinterpret_cast<const f32x4*>(p.shift + c);
   if (active && p.bnr) {
     bmu = *reinterpret_cast<const f32x4*>(p.mean + c);
     bis = *reinterpret_cast<const f32x4*>(p.invstd + c);
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs p) {
             *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + c) = v;
             continue;
           }
+          v = v * esc + esh;
           if (p.stats) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -231,6 +240,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs p) {
             }
           }
           if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + pix * p.ldadd + c);
+          if (p.relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+          }
           *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + c) = v;
         }
       }
@@ -366,7 +379,8 @@ int semseg_wino_dy_transform_wgrad(const float* dy, int lddy, float* Yh, int ldo
 }
 
 int semseg_wino_output_transform(const float* M, int ldm, float* y, int ldy, const float* add, int ldadd, double* stats,
-                                 int nslot, int N, int H, int W, int C, int dil, hipStream_t stream) {
+                                 int nslot, const float* scale, const float* shift, int relu, int N, int H, int W, int C,
+                                 int dil, hipStream_t stream) {
   if (!M || !y || (C & 3) || (ldm & 3) || (ldy & 3) || ldm < C || ldy < C || (add && (ldadd & 3)) ||
       (stats && nslot < 1) || semseg_wino_tiles(N, H, W, dil) < 0)
     return SEMSEG_EINVAL;
@@ -375,6 +389,7 @@ int semseg_wino_output_transform(const float* M, int ldm, float* y, int ldy, con
   a.nslot = nslot > 0 ? nslot : 1;
   a.g = make_geo(N, H, W, dil);
   a.bnr = 0; a.act = nullptr; a.ybn = nullptr; a.mean = nullptr; a.invstd = nullptr; a.ldact = 0; a.ldybn = 0;
+  a.scale = scale; a.shift = shift; a.relu = relu;
   return launch_output(a, stream);
 }
 
@@ -389,6 +404,7 @@ int semseg_wino_output_transform_bnreduce(const float* M, int ldm, float* y, int
   a.M = M; a.y = y; a.add = add; a.stats = sums; a.ldm = ldm; a.ldy = ldy; a.ldadd = ldadd; a.C = C; a.nslot = nslot;
   a.g = make_geo(N, H, W, dil);
   a.bnr = 1; a.act = act; a.ybn = ybn; a.mean = mean; a.invstd = invstd; a.ldact = ldact; a.ldybn = ldybn;
+  a.scale = nullptr; a.shift = nullptr; a.relu = 0;
   return launch_output(a, stream);
 }
 

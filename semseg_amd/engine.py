@@ -120,15 +120,15 @@ class ConvL:
         self.mod = mod
         self.Co, self.Ci, self.R, self.S = w.shape
         self.stride, self.pad, self.dil = mod.stride[0], mod.padding[0], mod.dilation[0]
-        # Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convs of a TRAINING engine (csrc/winograd.hip): 1 / 2.25 of the
+        # Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convs (csrc/winograd.hip): 1 / 2.25 of the
         # multiplications, the 16 GEMMs as one batched matrix-core launch.  Measured per shape at bs 16
         # (scripts/wino_bench.py, forward / data gradient / weight gradient, us): cls.0 15170 / 15240 / 17280 -> 8330 /
         # 8420 / 7130, layer4 conv2 1957 / 1948 / 2155 -> 1343 / 1295 / 1367, layer3 conv2 608 / 616 / 613 -> 427 / 393 /
         # 341; below 128 channels the transforms (HBM-bound) eat the gain (layer1 conv2: 152 -> 231), so those stay
         # direct.  Channel counts: K % 64 for the K-major GEMM, Co % 128 so that no padded column exists.
-        # Eval engines fold BatchNorm / ReLU / the residual into the direct kernel's epilogue and stay direct.
+        # Eval engines use it too: the output transform carries the folded BatchNorm scale / shift, ReLU and residual.
         self.wino = None
-        if (WINOGRAD and training and self.R == 3 and self.S == 3 and self.stride == 1 and self.pad == self.dil
+        if (WINOGRAD and self.R == 3 and self.S == 3 and self.stride == 1 and self.pad == self.dil
                 and self.Ci % 64 == 0 and self.Ci >= 128 and self.Co % 128 == 0 and mod.bias is None):
             self.wino = ops.WinoConv(self.Co, self.Ci, device, need_dgrad)
             self.pk = None
@@ -400,8 +400,17 @@ class Engine:
             ld = cl.Co if cl.Co % 64 == 0 else ops.roundup(cl.Co, 128)
             out = self.act(x.N, Ho, Wo, cl.Co, ld=ld, tag="conv")
         if cl.wino is not None:
-            assert fold is None and not bias and self.training
+            assert not bias
             T = ops.wino_tiles(x.N, x.H, x.W, cl.dil)
+            if not self.training:
+                # eval: the transformed input is scratch; BatchNorm (running statistics) / ReLU / residual ride in the
+                # output transform exactly as they ride in the direct kernel's epilogue
+                sc, sh, relu, res = fold if fold is not None else (None, None, False, None)
+                self._wino_rows(x.data, x.ld, cl.Ci, cl.wino.U_fwd, cl.wino.Co_pad, out.data, out.ld, cl.Co, x.N, x.H,
+                                x.W, cl.dil, T, self._wino_scratch("Vdy", 16 * T * cl.Ci), add=None if res is None else
+                                res.data, ldadd=0 if res is None else res.ld, fold=(sc, sh, relu))
+                return out
+            assert fold is None
             V = self.buf((16 * T * cl.Ci,), tag="winoV")      # kept: the weight gradient contracts it with dy
             self._wino_rows(x.data, x.ld, cl.Ci, cl.wino.U_fwd, cl.wino.Co_pad, out.data, out.ld, cl.Co, x.N, x.H, x.W,
                             cl.dil, T, V, stats=stats)
@@ -503,7 +512,7 @@ class Engine:
         return t
 
     def _wino_rows(self, src, lds, K, U, rows_pad, dst, ldd, Nout, N, H, W, d, T, V, stats=None, add=None, ldadd=0,
-                   bnr=None):
+                   bnr=None, fold=None):
         """input transform -> 16 batched row GEMMs [T x K] x [K x Nout] -> output transform: the forward of a Winograd conv
         (src = x, U = U_fwd) and its data gradient (src = dy, U = the flipped / transposed filter)."""
         px = N * H * W
@@ -521,8 +530,9 @@ class Engine:
             ops.wino_output_transform_bnreduce(Mb, Nout, dst, ldd, N, H, W, Nout, d, act, ldact, ybn, ldybn, mean,
                                                invstd, sums, ops.NSLOT, add=add, ldadd=ldadd)
         else:
+            sc, sh, relu = fold if fold is not None else (None, None, False)
             ops.wino_output_transform(Mb, Nout, dst, ldd, N, H, W, Nout, d, add=add, ldadd=ldadd, stats=stats,
-                                      nslot=ops.NSLOT)
+                                      nslot=ops.NSLOT, scale=sc, shift=sh, relu=relu)
         self._t1(ev)
 
     def _conv_bwd_wino(self, x, y, cl, m, V, T):

@@ -241,9 +241,10 @@ def wino_dy_transform_wgrad(dy, lddy, Yh, ldo, N, H, W, C, dil):
         "wino_dy_transform_wgrad")
 
 
-def wino_output_transform(M, ldm, y, ldy, N, H, W, C, dil, add=None, ldadd=0, stats=None, nslot=1):
-    _ck(lib.semseg_wino_output_transform(_p(M), ldm, _p(y), ldy, _p(add), ldadd, _p(stats), nslot, N, H, W, C, dil,
-                                         _stream()), "wino_output_transform")
+def wino_output_transform(M, ldm, y, ldy, N, H, W, C, dil, add=None, ldadd=0, stats=None, nslot=1, scale=None,
+                          shift=None, relu=False):
+    _ck(lib.semseg_wino_output_transform(_p(M), ldm, _p(y), ldy, _p(add), ldadd, _p(stats), nslot, _p(scale), _p(shift),
+                                         int(relu), N, H, W, C, dil, _stream()), "wino_output_transform")
 
 
 def wino_output_transform_bnreduce(M, ldm, y, ldy, N, H, W, C, dil, act, ldact, ybn, ldybn, mean, invstd, sums, nslot,

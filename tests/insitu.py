@@ -168,7 +168,7 @@ class InsituChecker:
             if x.bn_reduced:
                 # this launch also did the BatchNorm-backward reduction of the layer that produced x: what it stored is
                 # g = dx * (x > 0); the sums it accumulated are checked by the BatchNorm entry (dgamma / dbeta / dy)
-                qty = "dgrad+bnr"
+                qty = "dgrad+bnr" + wino
                 if x.bnsrc["relu"]:
                     gx64 = gx64 * (xs > 0)
                     gx32 = gx32 * (xs > 0)

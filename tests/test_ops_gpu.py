@@ -761,6 +761,13 @@ def test_winograd_conv_fwd_dgrad_wgrad(case, report):
     s = st.view(ops.NSLOT, 2, Co).sum(0).cpu()
     ref_s = torch.stack([y64.detach().sum((0, 2, 3)), (y64.detach() ** 2).sum((0, 2, 3))])
     e_s = float((s - ref_s).abs().max() / ref_s.abs().max())
+    # eval-mode epilogue: y = relu(conv * scale + shift + residual)
+    sc, sh = torch.rand(Co, device=DEV) + 0.5, torch.randn(Co, device=DEV)
+    res = torch.randn(N, H, W, ldy, device=DEV)
+    ye = torch.full((N, H, W, ldy), float("nan"), device=DEV)
+    ops.wino_output_transform(Mbuf, Co, ye, ldy, N, H, W, Co, d, add=res, ldadd=ldy, scale=sc, shift=sh, relu=True)
+    ref_e = torch.relu(nhwc(y64.detach()) * sc.double().cpu() + sh.double().cpu() + res[..., :Co].double().cpu())
+    assert relerr(ye[..., :Co], ref_e) < 2e-5
     # data gradient, accumulated onto an existing gradient
     dyb = torch.zeros(N, H, W, ldy, device=DEV)
     dyb[..., :Co] = nhwc(dy).to(DEV)
