@@ -24,7 +24,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 ISO_STEPS = 2
-PMC_FILE = "r02_pmc_per_kernel.json"   # per-kernel HBM bytes / MFMA-busy from the rocprofv3 --pmc passes of this round
+PMC_FILE = "r03_pmc_per_kernel.json"   # per-kernel HBM bytes / MFMA-busy from the rocprofv3 --pmc passes of this round
 
 
 def conv_flops_per_image(model, size):

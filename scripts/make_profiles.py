@@ -28,7 +28,7 @@ w = agg(os.path.join(g, tag + "_write", "pmc_counter_collection.csv"))
 m = agg(os.path.join(g, tag + "_mfma", "pmc_counter_collection.csv"))
 res = {}
 for k in f:
-    if not any(t in k for t in ("conv_igemm", "conv_wgrad", "bn_", "splitk")): continue
+    if not any(t in k for t in ("conv_igemm", "conv_wgrad", "bn_", "splitk", "wino_")): continue
     n = f[k]['launches']
     fetch = f[k]['FETCH_SIZE'] * 1024 * 2 / n
     write = w.get(k, {}).get('WRITE_SIZE', 0) * 1024 / max(w.get(k, {}).get('launches', 1), 1)

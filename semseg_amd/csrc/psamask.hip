@@ -256,7 +256,7 @@ int launch_plane(const float* src, float* dst, int N, int H, int W, int mH, int 
   const long long groups = (long long)N * H;
   // pieces of the slab loop: enough workgroups to keep loads in flight on every CU.  Measured (N, H, mask): (16, 30, 59)
   // 39 / 31 / 33 / 30 us for 1 / 2 / 4 / 8 pieces, (2, 30, 59) 26 / 15 / 10 / 8 us, (16, 45, 89) 215 / 215 / 211 / 204 us
-  // (that shape is bound by whole-line traffic of the mask tensor)
+  // (that shape moves runs of ~90 contiguous bytes: 4.1 TB/s of bytes moved by PMC whatever the piece count)
   int seg = 1;
   while (groups * seg < 768 && seg < 8) seg *= 2;
   a.seg = seg;
