@@ -12,12 +12,11 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ARCH = sys.argv[3] if len(sys.argv) > 3 else "psp"
 SIZE = 473 if ARCH == "psp" else 465
-# "policy/side/hipri/convdma": policy = SEMSEG_WGRAD_DMA value (a variant number or "small:big:tile-threshold"),
-# convdma = SEMSEG_CONV_DMA (forward / data-gradient kernel: 0 register-staged, 1 direct-to-LDS, 2 only 3x3, 3 only 1x1)
-# optional 5th field: extra environment "KEY=VAL+KEY=VAL" read per launch by the library (e.g. SEMSEG_CONV_TL=0)
-CONFIGS = [(c.split("/")[0], int(c.split("/")[1]), int(c.split("/")[2]), int(c.split("/")[3]),
-            c.split("/")[4] if len(c.split("/")) > 4 else "") for c in
-           os.environ.get("CONFIGS", "0/0/0/0,3/1/1/0,3/1/1/1,6/1/1/0,6/1/1/1,7/1/1/1,3/1/1/2,3/1/1/3,6/0/0/1").split(",")]
+# "policy/side/hipri[/extra]": policy = SEMSEG_WGRAD_DMA value (a variant number or "small:big:tile-threshold");
+# extra = "KEY=VAL+KEY=VAL": NSIDE (Engine.n_side), FUSE_BNR (Engine.fuse_bnr), anything else goes to the environment
+CONFIGS = [(c.split("/")[0], int(c.split("/")[1]), int(c.split("/")[2]), 0,
+            c.split("/")[3] if len(c.split("/")) > 3 else "") for c in
+           os.environ.get("CONFIGS", "0/0/0,6/1/0,6/1/1,6/0/0,7/1/1").split(",")]
 torch.manual_seed(0)
 if ARCH == "psp":
     from model.pspnet import PSPNet
@@ -46,7 +45,6 @@ for r in range(ROUNDS):
             if kv.split("=")[0] == "FUSE_BNR":       # BatchNorm-backward reduction in the data-gradient epilogue
                 eng.fuse_bnr = kv.split("=")[1] == "1"
         os.environ["SEMSEG_WGRAD_DMA"] = str(dma)
-        os.environ["SEMSEG_CONV_DMA"] = str(cdma)
         eng.side_all, eng.hipri_main = bool(side), bool(hipri)
         tr.step(x, y, 0.01)
         torch.cuda.synchronize()
@@ -57,5 +55,5 @@ for r in range(ROUNDS):
         res[c].append((time.time() - t0) / 5 * 1e3)
 print("%s batch %d: ms per step (min over %d rounds / all)" % (ARCH, B, ROUNDS))
 for c in CONFIGS:
-    print("  wgrad %-8s side_all %d hipri %d conv_dma %d %-18s: %8.2f   %s" % (c + (min(res[c]), " ".join("%.2f" % v for v in res[c]))))
+    print("  wgrad %-8s side_all %d hipri %d %-18s: %8.2f   %s" % (c[0], c[1], c[2], c[4], min(res[c]), " ".join("%.2f" % v for v in res[c])))
 print("final loss", float(ml.item()))

@@ -1339,17 +1339,14 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   p.ldpart = p.tiles_n * BN;
   const bool can_split = scratch && (a.ldy & 3) == 0 && a.ldy >= ((a.Nout + 3) & ~3) && KT >= 8;
   if (can_split && tiles < 384) {
-    static const int target = getenv("SEMSEG_SPLITK_TARGET") ? atoi(getenv("SEMSEG_SPLITK_TARGET")) : 448;
+    const int target = 448;   // workgroups aimed at; swept 320 ... 768 at batch 2 / 4
     ksplit = (target + tiles - 1) / tiles;
     if (ksplit > KT / 4) ksplit = KT / 4;
     if (ksplit > 16) ksplit = 16;
     full_tiles = 0;
     tail_mt = tiles_m;
   } else if (can_split) {
-    // SEMSEG_TAIL_SPLIT (read per call, A/B): 0 = no stream-K tail (the last partial round runs whole tiles), n > 1 =
-    // cap of the tail's K split (default 16)
-    const char* ts = getenv("SEMSEG_TAIL_SPLIT");
-    const int tcap = ts ? atoi(ts) : 16;
+    const int tcap = 16;   // cap of the tail's K split
     const int rem = tiles % P;
     if (tcap > 1 && rem != 0 && rem <= 208) {
       tail_mt = (rem + p.tiles_n - 1) / p.tiles_n;
@@ -1379,10 +1376,7 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   p.div_w = make_fastdiv(a.Wout);
   p.div_tn = make_fastdiv(p.tiles_n);
   p.div_ks = make_fastdiv(ksplit);
-  {
-    const char* gm_s = getenv("SEMSEG_CONV_GM");   // read per call (A/B): 0/1 = row-major tile order
-    p.gm = gm_s ? atoi(gm_s) : 8;
-  }
+  p.gm = 8;   // tile rows per group of the workgroup order (decode_tile)
   const int grid = p.full_tiles + (tiles - p.full_tiles) * ksplit;
   // buffer-load kernels need 1x1 / 3x3 taps, split points on chunk boundaries and < 2 GB operands
   const int RSv = a.R * a.S;
@@ -1392,13 +1386,11 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
   // Two-level accumulation whenever the reduction is longer than one flush interval (K > 576).  Round 1 used it for
   // K >= 4096 only; the in-situ backward test of round 2 showed single chains of K = 1152 ... 2304 (aux.0 /
   // layer0.6 data gradients) at 2.7-2.9x the rounding noise (rms) of the CPU's blocked sums, 6x in the maximum.
-  // SEMSEG_CONV_TL=0 restores the round-1 rule (A/B only).
-  const char* tl_s = getenv("SEMSEG_CONV_TL");
   // what counts is the chain one workgroup accumulates: the whole reduction for unsplit tiles, one K slice when
   // every tile is split (small per-GPU batch: slices are <= 18 K-steps there and the leaner kernel is 5 % faster
   // over the whole bs-2 step)
   const int chain = p.full_tiles > 0 ? KT : p.kt_per;
-  const bool tl = (tl_s && tl_s[0] == '0') ? (BN == 128 && KT >= 128) : chain > 18;
+  const bool tl = chain > 18;
 #define LAUNCH_CONV_(BM_, BN_, TR_, RS_, TL_) \
   conv_igemm_kernel<BM_, BN_, TR_, RS_, TL_><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p)
 #define LAUNCH_CONV(BM_, BN_, TR_, RS_)                                        \
@@ -1562,9 +1554,8 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   // tiles, so that the ~64 workgroups an XCD holds at a time touch few distinct operand blocks.  Measured per shape
   // with FETCH_SIZE (scripts/wgrad_traffic.py): cls.0 34.2 -> 6.1 GB, aux.0 1.57 -> 0.67 GB,
   // layer4 3x3 1.25 -> 0.81 GB, layer4 1x1 0.9 -> 0.64 GB per launch; 2.79x -> 1.4x the algorithmic bytes over the
-  // step's launch mix.  SEMSEG_WGRAD_ORDER = 0|1|2 forces one order (read per call: tuning scripts).
-  const char* order_s = getenv("SEMSEG_WGRAD_ORDER");
-  a.order = order_s ? atoi(order_s) : (RS > 1 ? 1 : (a.tiles_co < a.tiles_ci ? 1 : 0));
+  // step's launch mix.
+  a.order = RS > 1 ? 1 : (a.tiles_co < a.tiles_ci ? 1 : 0);
   scratch_floats /= batch;   // every batch item owns its own slab set
   // Direct-to-LDS variants of the 128 x 128 kernel (1..5 = K-step / ring depth / residency; 0 = register-staged
   // kernel).  They need byte offsets below 2^31 for both operands.
@@ -1591,11 +1582,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   static const int occ_of[8] = {3, 2, 3, 2, 5, 5, 2, 2};
   // Fill whole residency rounds (256 CUs x resident workgroups per CU): among the K splits that give at most two
   // rounds, take the one with the best fill (ties: fewer splits = fewer slabs to write and reduce).
-  // SEMSEG_WGRAD_FILL = n (read per call): aim at 1/n of a residency round — the engine runs n weight gradients
-  // side by side on n streams, each with a proportionally smaller K split (longer K loops, fewer slabs)
-  const char* fill_s = getenv("SEMSEG_WGRAD_FILL");
-  const int fill = fill_s ? (atoi(fill_s) > 0 ? atoi(fill_s) : 1) : 1;
-  const int ROUND = 256 * occ_of[dma] / fill;
+  const int ROUND = 256 * occ_of[dma];
   const int wg1 = tiles * batch;     // workgroups per K slice
   int ksplit = 1;
   {

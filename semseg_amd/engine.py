@@ -227,15 +227,16 @@ class Engine:
         # kernels and the data-gradient GEMMs of the main stream are co-resident with it instead of running alone
         # (measured bs 16: 217.4 -> 207.9 ms per step together with the high-priority chain below, 214.5 without
         # the side stream; scripts/step_variants.py).
-        self.side_all = os.environ.get("SEMSEG_SIDE_WGRAD_ALL", "1") == "1"
+        self.side_all = True
         # The dependent chain of backward (data gradients + BatchNorm) runs on a high-priority stream so that it wins
         # the dispatch race against the weight gradients queued on the side stream.
         # Not under torch.distributed: with the SyncBN all-reduces issued from the high-priority stream the forced
         # 1-rank RCCL step at batch 2 takes 60.5 ms instead of 39.2 (RCCL's own stream has normal priority and every
         # collective is an event round trip between the two).
         self.hipri_main = os.environ.get("SEMSEG_HIPRI_MAIN", "1") == "1" and not self.dist_on
-        # number of weight-gradient streams used round-robin (each with its own split-K scratch)
-        self.n_side = int(os.environ.get("SEMSEG_SIDE_STREAMS", "1"))
+        # number of weight-gradient streams used round-robin (each with its own split-K scratch); 2 / 3 / 4 measured
+        # slower than 1
+        self.n_side = 1
         # fold bn_bwd_reduce into the epilogue of the data gradient that completes a BatchNorm output's gradient
         self.fuse_bnr = os.environ.get("SEMSEG_FUSE_BNR", "1") == "1"
         self._sides, self._scr2s, self._side_rr = [], [], 0
