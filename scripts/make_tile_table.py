@@ -1,7 +1,7 @@
 """Regenerate semseg_amd/tile_table.json on an MI355X: for every forward / data-gradient shape of the BASELINE.json
 configurations (PSPNet-101 473^2 at per-GPU batch 16 / 8 / 4 / 2, PSANet-101 465^2 at 16 / 2, PSPNet-101 713^2 at 2)
-time 128 x 128 against 128 x 64 tiles on real operands (semseg_amd.ops._tuned_tile, 3 interleaved rounds of 3 launches,
-device idle) and keep 64 where it wins by >= 3 %.  The table is committed; nothing times tiles at run time.
+time the four tile shapes (128 x 128, 128 x 64, 64 x 128, 64 x 64) on real operands (semseg_amd.ops._tuned_tile, 3
+interleaved rounds of 3 launches, device idle) and keep 128 x 128 unless another shape wins by >= 3 %.  The table is committed; nothing times tiles at run time.
 
     SEMSEG_TILE_TUNE=1 python scripts/make_tile_table.py [out.json]        (GPU box; copy the result into semseg_amd/)
 """
@@ -41,12 +41,12 @@ if __name__ == "__main__":
         del tr, m, x, y
         torch.cuda.empty_cache()
     tiles = dict(sorted(ops.TILE_CHOICE.items()))
-    doc = {"generated_by": "scripts/make_tile_table.py (3 x 3 launches per width, 64 kept when >= 3 % faster)",
+    doc = {"generated_by": "scripts/make_tile_table.py (3 x 3 launches per tile shape; 128 x 128 unless another wins by >= 3 %)",
+           "tile_codes": "128 = 128x128, 64 = 128x64, 1128 = 64x128, 1064 = 64x64 (rows x columns)",
            "configs": ["%s%d_%d_c%d_bs%d" % c for c in CONFIGS],
            "tiles": tiles,
-           "ms_128_vs_64": {k: list(v) for k, v in sorted(ops.TILE_TIMES.items())}}
+           "ms_per_tile_code": {k: {str(c): t for c, t in v.items()} for k, v in sorted(ops.TILE_TIMES.items())}}
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as f:
         json.dump(doc, f, indent=0, sort_keys=False)
-    n64 = sum(1 for v in tiles.values() if v == 64)
-    print("wrote %s: %d shapes, %d run 128 x 64 tiles" % (out, len(tiles), n64))
+    print("wrote %s: %d shapes, by tile code %s" % (out, len(tiles), {c: sum(1 for v in tiles.values() if v == c) for c in ops.TILE_CODES}))

@@ -1321,9 +1321,15 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
   return semseg_launch_status();
 }
 
-static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratch,
+// tile code of the C ABI: 128 / 64 = 128-row tiles, that many output columns; 1128 / 1064 = 64-row tiles (2 waves), for
+// launches whose 128-row grid would not fill the chip (small per-GPU batch) — 4x the tiles of a 128 x 128 grid without
+// splitting K, so no partial slabs and no separate epilogue pass
+static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064 || t == 1128; }
+
+static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, float* scratch,
                        size_t scratch_floats, hipStream_t stream) {
-  constexpr int BMr = 128;
+  const int BMr = tile_code >= 1000 ? 64 : 128;
+  const int BN = tile_code % 1000;
   const int tiles_m = (a.M + BMr - 1) / BMr;
   ConvArgs p = a;
   if (p.batch > 1) { scratch = nullptr; scratch_floats = 0; }   // batched GEMM: the batch fills the chip, no split-K
@@ -1404,10 +1410,14 @@ static int conv_launch(bool transposed, const ConvArgs& a, int BN, float* scratc
     else if (bl) LAUNCH_CONV(BM_, BN_, TR_, 1);                    \
     else LAUNCH_CONV(BM_, BN_, TR_, 0);                            \
   } while (0)
-  if (BN == 128) {
+  if (BMr == 128 && BN == 128) {
     if (transposed) LAUNCH_RS(128, 128, true); else LAUNCH_RS(128, 128, false);
-  } else {
+  } else if (BMr == 128) {
     if (transposed) LAUNCH_RS(128, 64, true); else LAUNCH_RS(128, 64, false);
+  } else if (BN == 128) {
+    if (transposed) LAUNCH_RS(64, 128, true); else LAUNCH_RS(64, 128, false);
+  } else {
+    if (transposed) LAUNCH_RS(64, 64, true); else LAUNCH_RS(64, 64, false);
   }
 #undef LAUNCH_RS
 #undef LAUNCH_CONV
@@ -1447,7 +1457,7 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
                     int dil, const float* bias, const float* scale, int relu, const float* add,
                     int ldadd, double* stats, int stats_nslot, int tile_n, float* scratch,
                     size_t scratch_floats, hipStream_t stream) {
-  if (!x || !w_fwd || !y || Ci % 32 != 0 || (ldx & 3) || (tile_n != 64 && tile_n != 128))
+  if (!x || !w_fwd || !y || Ci % 32 != 0 || (ldx & 3) || !tile_code_ok(tile_n))
     return SEMSEG_EINVAL;
   ConvArgs a;
   a.x = x; a.w = w_fwd; a.y = y; a.bias = bias; a.scale = scale; a.relu = relu; a.add = add; a.stats = stats;
@@ -1463,7 +1473,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
                       int pad, int dil, const float* add, int ldadd, int tile_n, const ConvArgs* bnr, float* scratch,
                       size_t scratch_floats, hipStream_t stream) {
-  if (!dy || !w_dgrad || !dx || (lddy & 3) || (tile_n != 64 && tile_n != 128)) return SEMSEG_EINVAL;
+  if (!dy || !w_dgrad || !dx || (lddy & 3) || !tile_code_ok(tile_n)) return SEMSEG_EINVAL;
   const int Kc = (Co + 31) / 32 * 32;
   if (lddy < Kc) return SEMSEG_EINVAL;
   ConvArgs a;

@@ -420,7 +420,7 @@ class Engine:
             self.push("conv", lambda: self._conv_bwd_wino(x, out, cl, m, V, T), x=x, y=out, cl=cl, m=m)
             return out
         tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld)
-        ev = self._t0("conv_igemm_kernel<128,%d,false,%d>(+splitk_epilogue)" % (tile, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
+        ev = self._t0("conv_igemm_kernel<%d,%d,false,%d>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
         if fold is not None:
             sc, sh, relu, res = fold
             ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
@@ -487,7 +487,7 @@ class Engine:
             fuse = (self.fuse_bnr and last and bs is not None and x.C % 4 == 0 and x.ld % 4 == 0 and
                     all(yk.ld % 4 == 0 for yk, _ in bs["bns"]))
             tile = ops.chosen_tile("dgrad", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, y.ld, x.ld)
-            ev = self._t0("conv_igemm_kernel<128,%d,true,%d>(+splitk_epilogue)" % (tile, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), flops)
+            ev = self._t0("conv_igemm_kernel<%d,%d,true,%d>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), flops)
             if fuse:
                 ops.conv_dgrad_bnreduce(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
                                         x.data if bs["relu"] else None, x.ld,

@@ -100,6 +100,7 @@ TILE_CHOICE = load_tile_table()
 
 
 def _tuned_tile(key, dflt, device, out_floats, launch):
+    codes = TILE_CODES if dflt == 128 else (64, 1064)
     """Table lookup; with SEMSEG_TILE_TUNE=1 an unknown shape is timed once (launch(tile, out_tensor) -> return code of a
     side-effect-free launch of this shape into a scratch output on the operands' device)."""
     t = TILE_CHOICE.get(key)
@@ -110,22 +111,27 @@ def _tuned_tile(key, dflt, device, out_floats, launch):
     tmp = torch.empty(out_floats, dtype=torch.float32, device=device)
     torch.cuda.synchronize(device)
     best = {}
-    for tile in (128, 64, 128, 64, 128, 64):
-        _ck(launch(tile, tmp), "tile tuning")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
+    for rnd in range(3):
+        for tile in codes:
             _ck(launch(tile, tmp), "tile tuning")
-        e1.record()
-        e1.synchronize()
-        best[tile] = min(best.get(tile, 1e30), e0.elapsed_time(e1))
-    t = 64 if best[64] < 0.97 * best[128] else 128
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                _ck(launch(tile, tmp), "tile tuning")
+            e1.record()
+            e1.synchronize()
+            best[tile] = min(best.get(tile, 1e30), e0.elapsed_time(e1))
+    # the default shape (128 x 128, or 128 x 64 for layers with < 128 output columns) unless another wins by >= 3 %
+    t = min(codes, key=lambda c: best[c])
+    if best[t] >= 0.97 * best[dflt]:
+        t = dflt
     TILE_CHOICE[key] = t
-    TILE_TIMES[key] = (round(best[128] / 3, 4), round(best[64] / 3, 4))
+    TILE_TIMES[key] = {c: round(best[c] / 3, 4) for c in codes}
     return t
 
 
-TILE_TIMES = {}   # key -> (ms with 128-wide tiles, ms with 64-wide tiles), filled in tuning mode only
+TILE_CODES = (128, 64, 1128, 1064)   # 128x128, 128x64, 64x128, 64x64 (rows x columns; include/semseg_hip.h)
+TILE_TIMES = {}   # key -> {tile code: ms per launch}, filled in tuning mode only
 
 
 def _scr(scratch):
@@ -142,9 +148,9 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
     tile = pk.tile_fwd
-    if tile == 128:
+    if True:
         ldt = roundup(pk.Co, 4)
-        tile = _tuned_tile(tile_key("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), 128, x.device,
+        tile = _tuned_tile(tile_key("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), tile, x.device,
                            N * Ho * Wo * ldt,
                            lambda t, out: lib.semseg_conv_fwd(
                                _p(x), ldx, _p(pk.w_fwd), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
@@ -158,16 +164,14 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
 def chosen_tile(kind, pk, N, H, W, stride, pad, dil, ld_in, ld_out):
     """Tile width the (already measured) shape runs with; kind "fwd" | "dgrad".  For kernel-family labels."""
     dflt = pk.tile_fwd if kind == "fwd" else pk.tile_dgrad
-    if dflt != 128:
-        return dflt
     return TILE_CHOICE.get(tile_key(kind, N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), dflt)
 
 
 def _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch):
     tile = pk.tile_dgrad
-    if tile == 128:
+    if True:
         ldt = roundup(pk.Ci, 4)
-        tile = _tuned_tile(tile_key("dgrad", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), 128, dy.device,
+        tile = _tuned_tile(tile_key("dgrad", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), tile, dy.device,
                            N * H * W * ldt,
                            lambda t, out: lib.semseg_conv_dgrad(
                                _p(dy), lddy, _p(pk.w_dgrad), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S,

@@ -720,6 +720,41 @@ def test_conv_rounding_noise_vs_reduction_length(Ci, k, rows_n, report):
     assert errs[1] <= 3.0 * e_cpu + 1e-7 and errs[0] <= 4.0 * e_cpu + 1e-7
 
 
+@pytest.mark.parametrize("code", [128, 64, 1128, 1064])
+@pytest.mark.parametrize("case", [(2, 15, 15, 256, 256, 1, 1, 0, 1), (3, 13, 11, 128, 128, 3, 1, 2, 2), (2, 21, 21, 256, 512, 1, 2, 0, 1)])
+def test_conv_tile_codes(case, code, report, monkeypatch):
+    """Every tile shape of the forward / data-gradient kernel (128x128, 128x64, 64x128, 64x64) on the same operands,
+    forced through the tile table: forward with statistics, data gradient, fused BatchNorm-backward reduction."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co, k, s_, p_, d = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (Ci * k * k) ** 0.5)
+    x64, w64 = x.double().requires_grad_(True), w.double()
+    y64 = F.conv2d(x64, w64, None, s_, p_, d)
+    Ho, Wo = y64.shape[2:]
+    dy = torch.randn(N, Co, Ho, Wo, generator=g)
+    y64.backward(dy.double())
+    pk = ops.PackedConv(Co, Ci, k, k, DEV)
+    pk.pack(w.to(DEV))
+    monkeypatch.setitem(ops.TILE_CHOICE, ops.tile_key("fwd", N, H, W, Ci, Co, k, k, s_, p_, d), code)
+    monkeypatch.setitem(ops.TILE_CHOICE, ops.tile_key("dgrad", N, H, W, Ci, Co, k, k, s_, p_, d), code)
+    xb = nhwc(x).to(DEV)
+    yb = torch.full((N, Ho, Wo, Co), float("nan"), device=DEV)
+    st = torch.zeros(ops.NSLOT * 2 * Co, dtype=torch.float64, device=DEV)
+    scratch = torch.empty(8 * 1024 * 1024, device=DEV)
+    ops.conv_fwd(xb, Ci, pk, yb, Co, N, H, W, s_, p_, d, stats=st, nslot=ops.NSLOT, scratch=scratch)
+    e_f = relerr(nchw(yb), y64.detach())
+    sref = torch.stack([y64.detach().sum((0, 2, 3)), (y64.detach() ** 2).sum((0, 2, 3))])
+    e_s = float((st.view(ops.NSLOT, 2, Co).sum(0).cpu() - sref).abs().max() / sref.abs().max())
+    dyb = nhwc(dy).to(DEV)
+    dxb = torch.full((N, H, W, Ci), float("nan"), device=DEV)
+    ops.conv_dgrad(dyb, Co, pk, dxb, Ci, N, H, W, s_, p_, d, scratch=scratch)
+    e_d = relerr(nchw(dxb), x64.grad)
+    report("conv tile code %d %s: fwd %.2e stats %.2e dgrad %.2e" % (code, case, e_f, e_s, e_d))
+    assert e_f < 2e-5 and e_s < 1e-5 and e_d < 2e-5
+
+
 WINO_CASES = [  # N, H, W, Ci, Co, dilation
     (2, 12, 12, 64, 64, 1),
     (1, 15, 13, 64, 96, 2),      # odd sizes: partial tiles in some phases
