@@ -195,7 +195,9 @@ int semseg_bilinear_nhwc_to_nchw(const float* x, int ldx, float* y, int N, int H
                                  int Wo, int C, hipStream_t stream);
 
 /* ---- fused head: upsample + CrossEntropyLoss(ignore_index) + argmax — model/pspnet.py:95,100-103,
- * tool/train.py:121.  acc2 = {sum of losses, valid-pixel count} (fp64), loss = acc2[0]/acc2[1]. */
+ * tool/train.py:121.  acc2 = THREE doubles {sum of losses, valid-pixel count, number of labels that are neither
+ * ignore_index nor in [0, C)} (fp64, zeroed by the call), loss = acc2[0]/acc2[1].  Out-of-range labels contribute nothing;
+ * torch's CrossEntropyLoss raises on them, so the caller must look at acc2[2] (semseg_amd.engine does, asynchronously). */
 int semseg_ce_head_fwd(const float* scores, int ld, const long long* label, float* lse,
                        long long* pred, double* acc2, float* loss, int N, int h, int w, int H, int W,
                        int C, int ignore_index, hipStream_t stream);

@@ -20,7 +20,7 @@ for C, h, H, amp in [(11, 8, 8, 1.0), (11, 8, 57, 1.0), (21, 10, 73, 3.0), (150,
         zb[..., :C] = z.permute(0, 2, 3, 1).to(DEV)
         lse = torch.empty(N, H, W, device=DEV)
         pred = torch.empty(N, H, W, dtype=torch.int64, device=DEV)
-        acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+        acc = torch.zeros(3, dtype=torch.float64, device=DEV)
         lossd = torch.empty(1, device=DEV)
         ops.ce_head_fwd(zb, ld, lab.to(DEV), lse, pred, acc, lossd, N, h, w, H, W, C, 255)
         # the fp64 accumulator before the final fp32 rounding of the loss

@@ -19,7 +19,8 @@ __device__ __forceinline__ void src_index(int o, int in, float scale, int& i0, i
   l = s - (float)i0;
 }
 
-// acc[0] += sum of per-pixel losses (fp64), acc[1] += number of non-ignored pixels (fp64)
+// acc[0] += sum of per-pixel losses (fp64), acc[1] += number of non-ignored pixels (fp64), acc[2] += number of labels
+// that are neither ignore_index nor a class id (torch's CrossEntropyLoss raises on those; the caller checks the count)
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ z, int ld,
                                                      const long long* __restrict__ label,
                                                      float* __restrict__ lse_out,
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ z
   const int total = N * H * W;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   double loss = 0.0, cnt = 0.0;
+  bool bad = false;
   if (pix < total) {
     const int n = pix / (H * W);
     const int rem = pix - n * H * W;
@@ -73,7 +75,13 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ z
       const float zy = p00[y] * a00 + p01[y] * a01 + p10[y] * a10 + p11[y] * a11;
       loss = (double)(lse - zy);
       cnt = 1.0;
+    } else if (y != (long long)ignore_index) {
+      bad = true;
     }
+  }
+  {
+    const unsigned long long m = __ballot(bad);      // rare path: one atomic per wave that saw an out-of-range label
+    if (m && (threadIdx.x & 63) == 0) atomic_add_f64(&acc[2], (double)__popcll(m));
   }
   // block reduce
   __shared__ double sl[4], sc[4];
@@ -319,7 +327,7 @@ int semseg_ce_head_fwd(const float* scores, int ld, const long long* label, floa
                        long long* pred, double* acc2, float* loss, int N, int h, int w, int H, int W,
                        int C, int ignore_index, hipStream_t stream) {
   if (!scores || !label || !lse || !acc2 || !loss || (ld & 3) || ld < ((C + 3) & ~3)) return SEMSEG_EINVAL;
-  if (hipMemsetAsync(acc2, 0, 2 * sizeof(double), stream) != hipSuccess) return SEMSEG_ELAUNCH;
+  if (hipMemsetAsync(acc2, 0, 3 * sizeof(double), stream) != hipSuccess) return SEMSEG_ELAUNCH;
   const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const int total = N * H * W;

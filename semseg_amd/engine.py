@@ -971,12 +971,43 @@ class Engine:
         N = scores.N
         lse = self.buf((N, H, W), tag="lse" + tag)
         pred = self.buf((N, H, W), dtype=torch.int64, tag="pred" + tag) if want_pred else None
-        acc = self.buf((2,), dtype=F64, tag="acc" + tag)
+        acc = self.buf((3,), dtype=F64, tag="acc" + tag)
         loss = self.buf((1,), tag="loss" + tag)
         ops.ce_head_fwd(scores.data, scores.ld, label, lse, pred, acc, loss, N, scores.H, scores.W, H, W,
                         scores.C, ignore_index)
         rec = dict(scores=scores, label=label, lse=lse, acc=acc, H=H, W=W, ignore=ignore_index)
         return loss, pred, rec
+
+    # Out-of-range class ids: torch's CrossEntropyLoss (the reference's criterion, tool/train.py:121) raises on them; the
+    # fused head counts them (acc[2]) and treats them as ignored.  The first step of an engine checks synchronously
+    # (label_check, below); every later step copies the count to pinned host memory behind the head kernel and the NEXT
+    # forward that finds the copy complete raises — no synchronisation on the training path.
+    def _watch_label_count(self, acc):
+        if getattr(self, "_lbl_ev", None) is not None:
+            return                      # an earlier copy is still in flight: look at that one first
+        if not hasattr(self, "_lbl_host"):
+            self._lbl_host = torch.zeros(1, dtype=F64).pin_memory()
+        self._lbl_host.copy_(acc[2:3], non_blocking=True)
+        self._lbl_ev = torch.cuda.Event()
+        self._lbl_ev.record()
+
+    def _poll_label_count(self, wait=False):
+        ev = getattr(self, "_lbl_ev", None)
+        if ev is None:
+            return
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._lbl_ev = None
+        nbad = int(self._lbl_host[0].item())
+        if nbad:
+            raise IndexError("Target out of bounds: %d label(s) of an earlier step were neither ignore_index nor in "
+                             "[0, %d) (counted by the fused loss head)" % (nbad, self.model.cls[4].weight.shape[0]))
+
+    def check_labels(self):
+        """Blocks until the label count of the last watched step is on the host and raises if it is non-zero."""
+        self._poll_label_count(wait=True)
 
     def ce_bwd(self, rec, gloss):
         s = rec["scores"]
@@ -1056,6 +1087,7 @@ class Engine:
         y = y.contiguous()
         h, w = self.out_hw()
         assert tuple(y.shape) == (self.N, h, w), "target must be [N,%d,%d]" % (h, w)
+        self._poll_label_count()
         if not self._labels_checked or os.environ.get("SEMSEG_CHECK_LABELS") == "1":
             # torch's CrossEntropyLoss raises on class ids outside [0, C); the fused head would silently ignore
             # them.  Checked on this engine's first step (one sync), every step with SEMSEG_CHECK_LABELS=1.
@@ -1067,6 +1099,7 @@ class Engine:
         x_tmp, feat = self._features(x)
         scores, aux = self.heads_train(feat, x_tmp)
         main_loss, pred, self._rec_main = self.ce(scores, y, h, w, ignore_index, True, "m")
+        self._watch_label_count(self._rec_main["acc"])
         aux_loss, _, self._rec_aux = self.ce(aux, y, h, w, ignore_index, False, "a")
         return pred, main_loss, aux_loss
 

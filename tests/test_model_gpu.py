@@ -295,7 +295,7 @@ def test_all_pixels_ignored_backward_is_zero_like_torch(report):
     scores = torch.randn(N, h, w, 128, device="cuda")
     label = torch.full((N, H, W), 255, dtype=torch.int64, device="cuda")
     lse = torch.empty(N, H, W, device="cuda")
-    acc = torch.zeros(2, dtype=torch.float64, device="cuda")
+    acc = torch.zeros(3, dtype=torch.float64, device="cuda")
     loss = torch.empty(1, device="cuda")
     ops.ce_head_fwd(scores, 128, label, lse, None, acc, loss, N, h, w, H, W, C, 255)
     assert torch.isnan(loss).item()
@@ -318,7 +318,22 @@ def test_out_of_range_labels_raise_like_torch(report):
         m(x, y)
     y[0, 3, 4] = 255
     m(x, y)
-    report("out-of-range label raises IndexError; ignore_index passes")
+    # later steps: the fused loss head counts out-of-range labels, the count travels to the host behind the step and the
+    # next forward that finds it raises (no synchronisation on the training path)
+    y2 = y.clone()
+    y2[1, 7, 7] = -3
+    y2[0, 0, 0] = 9
+    m(x, y2)                                  # not the engine's first step: nothing raises here ...
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError, match="2 label"):
+        m(x, y)                               # ... the next forward does
+    m(x, y)                                   # and the engine is usable again
+    eng = next(iter(m.__dict__["_engines"].values()))
+    m(x, y2)
+    with pytest.raises(IndexError):
+        eng.check_labels()                    # explicit, blocking form
+    report("out-of-range label raises IndexError (first step: at once; later steps: at the next forward); "
+           "ignore_index passes")
 
 
 def test_trainer_detects_broken_parameter_aliasing(report):

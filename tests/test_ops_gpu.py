@@ -420,7 +420,7 @@ def test_ce_head(C, h, H, report):
     labd = lab.to(DEV)
     lse = torch.empty(N, H, W, device=DEV)
     pred = torch.empty(N, H, W, dtype=torch.int64, device=DEV)
-    acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+    acc = torch.zeros(3, dtype=torch.float64, device=DEV)
     lossd = torch.empty(1, device=DEV)
     ops.ce_head_fwd(zb, ld, labd, lse, pred, acc, lossd, N, h, w, H, W, C, 255)
     dz = torch.full((N, h, w, ld), 7.0, device=DEV)
