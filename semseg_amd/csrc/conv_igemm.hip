@@ -1672,9 +1672,19 @@ int semseg_gemm_rows_batched(const float* a, int lda, long long a_bs, const floa
 int semseg_gemm_kmajor_batched(const float* x, int ldx, long long x_bs, const float* y, int ldy, long long y_bs,
                                float* out, long long out_bs, float* scratch, size_t scratch_floats, int K, int Ci,
                                int Co, int accumulate, int batch, hipStream_t stream) {
-  if (batch > 65535) return SEMSEG_EINVAL;
-  return wgrad_launch(x, ldx, y, ldy, out, scratch, scratch_floats, 1, K, 1, Ci, K, 1, Co, 1, 1, 1, 0, 1, accumulate,
-                      batch, x_bs, y_bs, out_bs, stream);
+  if (batch < 1 || batch > 65535) return SEMSEG_EINVAL;
+  // every batch item needs at least one partial slab of the scratch arena: a batch that does not fit runs in chunks
+  const size_t slab = semseg_conv_wgrad_scratch_floats(Ci, Co, 1, 1);
+  const size_t fit = slab ? scratch_floats / slab : 0;
+  if (fit < 1) return SEMSEG_EINVAL;
+  for (int b0 = 0; b0 < batch; b0 += (int)fit) {
+    const int nb = batch - b0 < (int)fit ? batch - b0 : (int)fit;
+    const int rc = wgrad_launch(x + (long long)b0 * x_bs, ldx, y + (long long)b0 * y_bs, ldy, out + (long long)b0 * out_bs,
+                                scratch, scratch_floats, 1, K, 1, Ci, K, 1, Co, 1, 1, 1, 0, 1, accumulate, nb, x_bs, y_bs,
+                                out_bs, stream);
+    if (rc != SEMSEG_OK) return rc;
+  }
+  return SEMSEG_OK;
 }
 
 size_t semseg_conv_wgrad_scratch_floats(int Ci, int Co, int R, int S) {

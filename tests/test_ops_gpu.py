@@ -839,3 +839,22 @@ def test_winograd_conv_fwd_dgrad_wgrad(case, report):
     e_w = relerr(dw, w64.grad)
     report("winograd %s: fwd %.2e stats %.2e dgrad %.2e wgrad %.2e" % (case, e_f, e_s, e_d, e_w))
     assert e_f < 2e-5 and e_d < 2e-5 and e_w < 2e-5 and e_s < 1e-5
+
+
+def test_gemm_kmajor_batched_chunks_when_scratch_is_small(report):
+    """a batch whose partial slabs do not fit the scratch arena runs in chunks instead of failing."""
+    from semseg_amd import ops
+    B, K, Ci, Co = 5, 300, 128, 128
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, K, Ci, generator=g).to(DEV)
+    y = torch.randn(B, K, Co, generator=g).to(DEV)
+    ref = torch.einsum("bko,bkc->boc", y.double().cpu(), x.double().cpu())
+    out = torch.full((B, Co, Ci), float("nan"), device=DEV)
+    scratch = torch.empty(2 * Co * Ci + 7, device=DEV)       # room for two slabs only -> chunks of 2, 2, 1
+    ops.gemm_kmajor_batched(x, Ci, K * Ci, y, Co, K * Co, out, Co * Ci, scratch, K, Ci, Co, B)
+    e = relerr(out, ref)
+    report("gemm_kmajor_batched in chunks (5 items, scratch for 2): %.2e" % e)
+    assert e < 2e-5
+    with pytest.raises(ops.HipError):
+        ops.gemm_kmajor_batched(x, Ci, K * Ci, y, Co, K * Co, out, Co * Ci, torch.empty(Co * Ci - 1, device=DEV), K, Ci,
+                                Co, B)
