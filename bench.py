@@ -332,7 +332,9 @@ def main():
     torch.cuda.empty_cache()
     loss_trainer = loss_val
     sec_module = loss_module = None
-    if args.module_steps > 0 or not primary_trainer:
+    # the second leg is a single-GPU comparison; in a multi-rank launch only the path that was asked for runs (a failure in
+    # an extra leg on one rank would hang the others in a collective)
+    if (args.module_steps > 0 and world == 1) or not primary_trainer:
         sec_module, loss_module = module_path_step_time(args, dev, world, rank, B,
                                                         args.module_steps if primary_trainer else args.steps,
                                                         2 if primary_trainer else args.warmup)
