@@ -1,3 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 600 python -m pytest tests/test_model_gpu.py tests/test_ops_gpu.py -m gpu -x -q -k "label or ce_head or ignored or golden" 2>&1 | tail -4
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --module-steps 0 --no-kernel-timing 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bs16', d['ms_per_step'], d['value'])"
+timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "winograd or psa_ops or gemm" 2>&1 | tail -2
+for pz in 0 1; do echo "== SEMSEG_GEMM_PIPE=$pz"; SEMSEG_GEMM_PIPE=$pz python scripts/conv_bench.py 2>&1 | grep "l3 conv3\|l4 conv3"; SEMSEG_GEMM_PIPE=$pz python scripts/wino_bench.py 16 2>&1 | grep "l3 conv2\|l4 conv2" | cut -c1-250; done
