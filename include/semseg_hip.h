@@ -126,6 +126,15 @@ int semseg_wino_output_transform_bnreduce(const float* M, int ldm, float* y, int
  * Kc >= Co); padding rows / columns are written as zero */
 int semseg_wino_filter_transform(const float* w_oihw, float* U, int Co, int Ci, int rows_pad, int Kc, int flip,
                                  hipStream_t stream);
+/* every filter panel of a network in one launch: descs_dev[i] describes one semseg_wino_filter_transform call, panel i
+ * owns blocks [block_starts_dev[i], block_starts_dev[i+1]) of 256 (row, k) pairs each */
+typedef struct SemsegWinoFilterDesc {
+  const float* w;   /* OIHW [Co][Ci][3][3] */
+  float* U;         /* [16][rows_pad][Kc] */
+  int Co, Ci, rows_pad, Kc, flip;
+} SemsegWinoFilterDesc;
+int semseg_wino_filter_transform_multi(const SemsegWinoFilterDesc* descs_dev, const int* block_starts_dev, int npanels,
+                                       int total_blocks, hipStream_t stream);
 int semseg_wino_filter_grad(const float* dU, float* dw_oihw, int Co, int Ci, int accumulate, hipStream_t stream);
 
 /* Stem conv 3->64, 3x3 stride 2 pad 1, reading the caller's NCHW input (model/resnet.py:108). */

@@ -1,3 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "winograd or psa_ops or gemm" 2>&1 | tail -2
-for pz in 0 1; do echo "== SEMSEG_GEMM_PIPE=$pz"; SEMSEG_GEMM_PIPE=$pz python scripts/conv_bench.py 2>&1 | grep "l3 conv3\|l4 conv3"; SEMSEG_GEMM_PIPE=$pz python scripts/wino_bench.py 16 2>&1 | grep "l3 conv2\|l4 conv2" | cut -c1-250; done
+timeout 600 python -m pytest tests/test_model_gpu.py tests/test_ops_gpu.py -m gpu -x -q -k "filter_panels or kmajor_batched_chunks or golden or variants" 2>&1 | tail -3
+run() { tag=$1; shift; "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', d['ms_per_step'], d['value'])"; }
+for b in 16 2; do run "bs$b" timeout 300 python bench.py --global-batch $b --no-cpu-baseline --steps 10 --warmup 3 --module-steps 0 --no-kernel-timing; done

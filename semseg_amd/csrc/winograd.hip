@@ -308,6 +308,49 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
   }
 }
 
+// All filter transforms of a network in ONE launch (31 convs x 2 panels per PSPNet-101 training step): block b finds
+// its panel by binary search over the block-start table, 256 (row, k) pairs per block.
+__global__ __launch_bounds__(256) void wino_filter_multi_kernel(const SemsegWinoFilterDesc* __restrict__ descs,
+                                                                const int* __restrict__ starts, int nseg) {
+  int lo = 0, hi = nseg - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const SemsegWinoFilterDesc d = descs[lo];
+  const long long idx = (long long)(b - starts[lo]) * 256 + threadIdx.x;
+  const long long total = (long long)d.rows_pad * d.Kc;
+  if (idx >= total) return;
+  const size_t plane = (size_t)total;
+  const int k = (int)(idx % d.Kc), row = (int)(idx / d.Kc);
+  const int co = d.flip ? k : row, ci = d.flip ? row : k;
+  float g[3][3];
+  const bool ok = co < d.Co && ci < d.Ci;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int rr = d.flip ? 2 - r : r, ss = d.flip ? 2 - s : s;
+      g[r][s] = ok ? d.w[((size_t)co * d.Ci + ci) * 9 + rr * 3 + ss] : 0.f;
+    }
+  float t[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    t[0][s] = g[0][s];
+    t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+    t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+    t[3][s] = g[2][s];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d.U[(size_t)(4 * i + 0) * plane + idx] = t[i][0];
+    d.U[(size_t)(4 * i + 1) * plane + idx] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+    d.U[(size_t)(4 * i + 2) * plane + idx] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+    d.U[(size_t)(4 * i + 3) * plane + idx] = t[i][2];
+  }
+}
+
 // dW = G^T dU G (3x3 from 4x4): dU[16][Co][Ci] -> OIHW gradient [Co][Ci][3][3] (= or +=).
 __global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Co,
                                                                int Ci, int accumulate) {
@@ -437,6 +480,13 @@ int semseg_wino_filter_transform(const float* w_oihw, float* U, int Co, int Ci, 
   if (!flip && (rows_pad < Co || Kc < Ci)) return SEMSEG_EINVAL;
   if (flip && (rows_pad < Ci || Kc < Co)) return SEMSEG_EINVAL;
   wino_filter_kernel<<<grid_1d((long long)rows_pad * Kc), 256, 0, stream>>>(w_oihw, U, Co, Ci, rows_pad, Kc, flip);
+  return semseg_launch_status();
+}
+
+int semseg_wino_filter_transform_multi(const SemsegWinoFilterDesc* descs_dev, const int* block_starts_dev, int npanels,
+                                       int total_blocks, hipStream_t stream) {
+  if (!descs_dev || !block_starts_dev || npanels < 1 || total_blocks < 1) return SEMSEG_EINVAL;
+  wino_filter_multi_kernel<<<total_blocks, 256, 0, stream>>>(descs_dev, block_starts_dev, npanels);
   return semseg_launch_status();
 }
 

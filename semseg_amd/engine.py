@@ -338,9 +338,7 @@ class Engine:
         """One launch packs every conv weight (forward + data-gradient panels)."""
         import ctypes
         import numpy as np
-        for m, cl in self.convs.items():
-            if cl is not None and cl.wino is not None:
-                cl.wino.transform(m.weight.detach())
+        self._wino_filters()
         items = [(m, cl) for m, cl in self.convs.items() if cl is not None and cl.pk is not None]
         if not items:
             return
@@ -370,6 +368,35 @@ class Engine:
             self._pack_n = len(items)
             self._pack_ptrs = ptrs
         ops.conv_pack_weights_multi(self._pack_descs, self._pack_starts, self._pack_n, self._pack_blocks)
+
+    def _wino_filters(self):
+        """Every Winograd filter panel (forward + flipped data-gradient panel per conv) in one launch."""
+        import ctypes
+        import numpy as np
+        wl = [(m, cl.wino) for m, cl in self.convs.items() if cl is not None and cl.wino is not None]
+        if not wl:
+            return
+        ptrs = tuple(m.weight.data_ptr() for m, _ in wl)
+        if getattr(self, "_wf_ptrs", None) != ptrs:
+            class Desc(ctypes.Structure):
+                _fields_ = [("w", ctypes.c_void_p), ("U", ctypes.c_void_p), ("Co", ctypes.c_int), ("Ci", ctypes.c_int),
+                            ("rows_pad", ctypes.c_int), ("Kc", ctypes.c_int), ("flip", ctypes.c_int)]
+            panels = []
+            for m, wc in wl:
+                panels.append((m.weight.data_ptr(), wc.U_fwd.data_ptr(), wc.Co, wc.Ci, wc.Co_pad, wc.Ci, 0))
+                if wc.U_dgrad is not None:
+                    panels.append((m.weight.data_ptr(), wc.U_dgrad.data_ptr(), wc.Co, wc.Ci, wc.Ci_pad, wc.Kc, 1))
+            arr = (Desc * len(panels))()
+            starts, blk = [], 0
+            for i, pn in enumerate(panels):
+                arr[i] = Desc(*pn)
+                starts.append(blk)
+                blk += (pn[4] * pn[5] + 255) // 256
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            self._wf_descs = torch.from_numpy(raw).to(self.device)
+            self._wf_starts = torch.tensor(starts, dtype=torch.int32, device=self.device)
+            self._wf_n, self._wf_blocks, self._wf_ptrs = len(panels), blk, ptrs
+        ops.wino_filter_transform_multi(self._wf_descs, self._wf_starts, self._wf_n, self._wf_blocks)
 
     def _weights_sig(self):
         return tuple(p._version for p in self.params) + tuple(p.data_ptr() for p in self.params[:4])

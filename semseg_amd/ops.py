@@ -229,6 +229,11 @@ class WinoConv:
                                                  _stream()), "wino_filter_transform")
 
 
+def wino_filter_transform_multi(descs_dev, starts_dev, npanels, total_blocks):
+    _ck(lib.semseg_wino_filter_transform_multi(_p(descs_dev), _p(starts_dev), npanels, total_blocks, _stream()),
+        "wino_filter_transform_multi")
+
+
 def wino_tiles(N, H, W, dil):
     t = int(lib.semseg_wino_tiles(N, H, W, dil))
     if t < 0:

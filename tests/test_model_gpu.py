@@ -430,3 +430,25 @@ def test_layerwise_noise_tracks_cpu_fp32(report):
         if eh / max(ec, 1e-12) > worst[0]:
             worst = (eh / max(ec, 1e-12), name)
     report("layerwise train-mode noise, %d layers: worst hip/cpu32 error ratio %.2f at %s" % (len(seen), worst[0], worst[1]))
+
+
+def test_winograd_filter_panels_single_launch_equals_per_conv(report):
+    """Engine._wino_filters (every forward / flipped data-gradient filter panel of the network in one launch) against the
+    per-conv transform calls: bitwise."""
+    from model.pspnet import PSPNet
+    from semseg_amd import ops
+    from semseg_amd.engine import Engine
+    torch.manual_seed(3)
+    m = PSPNet(layers=50, classes=5, zoom_factor=8, dropout=0.0, pretrained=False).cuda().train()
+    eng = Engine(m, 2, 41, 41, True, "psp")
+    eng.pack_weights()
+    n = 0
+    for mod, cl in eng.convs.items():
+        if cl is None or cl.wino is None:
+            continue
+        ref = ops.WinoConv(cl.Co, cl.Ci, "cuda")
+        ref.transform(mod.weight.detach())
+        assert torch.equal(ref.U_fwd, cl.wino.U_fwd) and torch.equal(ref.U_dgrad, cl.wino.U_dgrad)
+        n += 1
+    assert n >= 10
+    report("Winograd filter panels: one launch for %d convs == per-conv transforms (bitwise)" % n)
