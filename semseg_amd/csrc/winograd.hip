@@ -462,7 +462,9 @@ int launch_output(const WinoOutArgs& a, hipStream_t stream) {
   while (tpr * 2 <= C4 && tpr * 2 <= 256) tpr *= 2;
   const int rpb = 256 / tpr, gx = (C4 + tpr - 1) / tpr;
   int gy = (a.g.T + rpb - 1) / rpb;
-  int cap = 4096 / gx;          // few blocks per channel group: every block ends in fp64 atomics
+  // few blocks per channel group: every block ends in one fp64 atomic pair per channel, and same-address atomics
+  // serialise (layer3's output transform, us, by the cap: 4096: 85, 2048: 69, 1024: 57, 512: 54, 256: 58)
+  int cap = 512 / gx;
   if (cap < 1) cap = 1;
   if (!stats) cap = 65535;
   if (gy > cap) gy = cap;
