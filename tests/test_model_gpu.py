@@ -452,3 +452,39 @@ def test_winograd_filter_panels_single_launch_equals_per_conv(report):
         n += 1
     assert n >= 10
     report("Winograd filter panels: one launch for %d convs == per-conv transforms (bitwise)" % n)
+
+
+def test_winograd_and_direct_training_trajectories_agree(report, monkeypatch):
+    """Six optimisation steps of the same PSPNet-50 from the same weights, once with the Winograd F(2x2,3x3) path and once
+    with every 3x3 conv on the direct kernels: identical first-step losses to fp32 noise, and the two fp32 trajectories
+    stay together (they may only drift by the usual amplification of rounding differences through ReLU flips)."""
+    from model.pspnet import PSPNet
+    from oracle import segnet
+    from semseg_amd import engine as E
+    from semseg_amd.trainer import Trainer
+    x, y = inputs(4, 73, 21)
+    x, y = x.cuda(), y.cuda()
+
+    def run(wino):
+        monkeypatch.setattr(E, "WINOGRAD", wino)
+        torch.manual_seed(0)
+        m = PSPNet(layers=50, classes=21, zoom_factor=8, dropout=0.0, pretrained=False)
+        m.load_state_dict(segnet.recipe_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=77))
+        tr = Trainer(m.cuda().train(), base_lr=0.01, sync_bn=False)
+        eng_uses = None
+        out = []
+        for _ in range(6):
+            _, ml, al = tr.step(x, y, 0.01)
+            out.append((float(ml), float(al)))
+            eng = next(iter(tr.engines.values()))
+            eng_uses = sum(1 for cl in eng.convs.values() if cl is not None and cl.wino is not None)
+        return out, eng_uses
+
+    a, na = run(True)
+    b, nb = run(False)
+    assert na >= 10 and nb == 0
+    rel = [max(abs(p[0] - q[0]) / abs(q[0]), abs(p[1] - q[1]) / abs(q[1])) for p, q in zip(a, b)]
+    report("Winograd vs direct training trajectory (PSPNet-50, 6 steps): relative loss difference per step %s"
+           % " ".join("%.1e" % r for r in rel))
+    assert rel[0] < 1e-5 and max(rel) < 2e-2
+    assert a[-1][0] < a[0][0] and b[-1][0] < b[0][0]          # both descend
