@@ -216,6 +216,49 @@ def module_path_step_time(args, dev, world, rank, B, steps, warmup):
     return dt / steps, loss_val
 
 
+def split_bf16_experiment(args, dev, B, steps=6, warmup=2):
+    """NOT the reported configuration: the same Trainer step with the forward and data-gradient
+    row GEMMs of every Winograd conv on the split-bf16 x6 kernel (fp32 operands cut into three bf16 pieces in flight,
+    six bf16 matrix-core products, fp32 accumulation; in-situ error no worse than the fp32 matrix-core kernel's).
+    Weight-gradient GEMMs, 1x1 convs and everything else stay on the fp32 instructions.  Single GPU only."""
+    from semseg_amd.trainer import Trainer
+    from semseg_amd import engine as E
+    old = (E.SPLIT_BF16, E.SPLIT_LAYERS)
+    E.SPLIT_BF16, E.SPLIT_LAYERS = 6, ["all"]
+    try:
+        torch.manual_seed(0)
+        if args.arch == "psp":
+            from model.pspnet import PSPNet
+            model = PSPNet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
+        else:
+            from model.psanet import PSANet
+            model = PSANet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
+        model = model.to(dev).train()
+        tr = Trainer(model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, aux_weight=0.4, sync_bn=True)
+        g = torch.Generator().manual_seed(1000)
+        x = torch.randn(B, 3, args.size, args.size, generator=g).to(dev)
+        y = torch.randint(0, args.classes, (B, args.size, args.size), generator=g).to(dev)
+        for _ in range(warmup):
+            tr.step(x, y, 0.01)
+        nsplit = sum(1 for e in tr.engines.values() for c in e.convs.values() if c is not None and c.split)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(steps):
+            ml = tr.step(x, y, 0.01)[1]
+        torch.cuda.synchronize()
+        sec = (time.time() - t0) / steps
+        loss = float(ml.item())
+        del tr, model
+        torch.cuda.empty_cache()
+    finally:
+        E.SPLIT_BF16, E.SPLIT_LAYERS = old
+    return {"what": "EXPERIMENT, not the reported configuration and not part of `value`: SEMSEG_SPLIT_BF16=6 "
+                    "SEMSEG_SPLIT_LAYERS=all - forward + data-gradient GEMMs of the Winograd convs as six bf16 "
+                    "matrix-core products of three-way split fp32 operands, fp32 accumulation (DESIGN.md section 8.4)",
+            "ms_per_step": round(sec * 1e3, 3), "images_per_sec": round(B / sec, 3), "steps": steps,
+            "convs_on_split_kernel": nsplit, "final_main_loss": round(loss, 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,6 +271,7 @@ def main():
     ap.add_argument("--arch", default="psp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-experiments", action="store_true", help="skip the labelled split-bf16 side measurement")
     ap.add_argument("--path", default="trainer", choices=["trainer", "module"],
                     help="trainer: the fused loop body (semseg_amd.Trainer) is the timed value and the drop-in nn.Module "
                          "+ torch.optim.SGD loop is timed beside it (module_path); module: the other way round")
@@ -342,6 +386,12 @@ def main():
         dt = sec_trainer * args.steps
     else:
         dt, loss_val = sec_module * args.steps, loss_module
+    experiment = None
+    if world == 1 and not args.no_experiments:
+        try:
+            experiment = split_bf16_experiment(args, dev, B)
+        except Exception as e:                       # a side measurement never takes the bench line down
+            experiment = {"error": repr(e)}
 
     if rank == 0:
         ips = args.global_batch * args.steps / dt
@@ -381,6 +431,8 @@ def main():
                          else "semseg_amd.Trainer fused step"),
                 "ms_per_step": round(other * 1e3, 3), "images_per_sec": round(args.global_batch / other, 3),
                 "steps": args.module_steps, "final_main_loss": round(loss_module if primary_trainer else loss_trainer, 5)}
+        if experiment is not None:
+            out["experiment_split_bf16x6"] = experiment
         if n_sync is not None:
             out["syncbn_collectives_per_step"] = n_sync
         if roof is not None:

@@ -97,6 +97,15 @@ int semseg_gemm_kmajor_batched(const float* x, int ldx, long long x_bs, const fl
                                float* out, long long out_bs, float* scratch, size_t scratch_floats, int K, int Ci,
                                int Co, int accumulate, int batch, hipStream_t stream);
 
+/* EXPERIMENT (engine flag SEMSEG_SPLIT_BF16, off by default and never part of the reported
+ * configuration): semseg_gemm_rows_batched with each fp32 operand split in flight into nsplit bf16 pieces (2: a*b ~
+ * ah*bh + ah*bl + al*bh, ~2^-16 per product; 3: six products, ~2^-23) and multiplied on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation.  Same operands and strides; bk = 16 | 32 (32 only with nsplit 2), K % bk == 0, lda % 4 == 0,
+ * Bt rows readable up to roundup(Nout, 128). */
+int semseg_gemm_rows_batched_bf16split(const float* a, int lda, long long a_bs, const float* bt, long long bt_bs,
+                                       float* c, int ldc, long long c_bs, int M, int K, int Nout, int batch, int nsplit,
+                                       int bk, hipStream_t stream);
+
 /* ---- Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convolutions (kernel 3, stride 1, padding = dilation:
  * model/resnet.py:63-69 as modified by model/pspnet.py:49-58; head convs model/pspnet.py:65,73).
  *   forward:        V = input_transform(x);  M[e] = V[e] * U[e]^T (semseg_gemm_rows_batched, batch 16);  y = output_transform(M)

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsemseg_hip.so")
 SOURCES = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip",
-           "psa_ops.hip", "infer.hip", "optim.hip", "augment.hip", "winograd.hip"]
+           "psa_ops.hip", "infer.hip", "optim.hip", "augment.hip", "winograd.hip", "gemm_bf16split.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared"]
 
 

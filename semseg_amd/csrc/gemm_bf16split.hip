@@ -1,0 +1,181 @@
+// EXPERIMENT, off by default (engine flag SEMSEG_SPLIT_BF16 = 3 | 6, never the reported configuration):
+// the batched row GEMM of the Winograd path,  C[b][M][Nout] = A[b][M][K] * Bt[b][Nout_pad][K]^T  (same operands,
+// same layouts and strides as semseg_gemm_rows_batched), with each fp32 operand split on the fly into bf16 pieces
+// and the product rebuilt from bf16 matrix-core instructions (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate)
+// with fp32 accumulation:
+//   nsplit 2 ("x3"):  x = h + l,      a*b ~ ah*bh + ah*bl + al*bh                       (3 MFMAs, ~2^-16 per product)
+//   nsplit 3 ("x6"):  x = h + m + l,  a*b ~ ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm  (6 MFMAs, ~2^-23)
+// The operands stay fp32 in HBM; the split happens in registers between the global load and the LDS store, so the
+// kernel is a drop-in for the fp32 one.  What it costs in accuracy is measured by scripts/split_bf16_probe.py and the
+// in-situ test; DESIGN.md section 8.4 has the numbers.
+//
+// Tile: 256 rows x 128 columns per workgroup of 8 waves (4 x 2, 64 x 64 each = 2 x 2 MFMA blocks), K staged BK at a
+// time: global -> registers (prefetched one stage ahead) -> split -> LDS [rows][BK] bf16 per piece (chunk-swizzled) ->
+// fragments.  Measured and set aside: experiments/gemm_bf16split_256sq.inc (256 x 256 tile, deeper pipeline).
+#include "common.h"
+#include "../../include/semseg_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+constexpr int SB_BM = 256, SB_BN = 128, SB_THREADS = 512;
+
+struct SplitArgs {
+  const float* a;
+  const float* bt;
+  float* c;
+  long long a_bs, bt_bs, c_bs;
+  int lda, ldc, M, K, Nout, tiles_m, tiles_n, total;
+};
+
+// x -> NS bf16 pieces (round to nearest even at every level; the remainders are exact in fp32)
+template <int NS>
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[NS]) {
+  f32x4 r = v;
+#pragma unroll
+  for (int c = 0; c < NS; ++c) {
+    out[c] = __builtin_convertvector(r, bf16x4);
+    if (c + 1 < NS) r -= __builtin_convertvector(out[c], f32x4);
+  }
+}
+
+template <int NS, int BK>
+__global__ __launch_bounds__(SB_THREADS) void gemm_rows_bf16split_kernel(const SplitArgs p) {
+  // LDS rows are BK bf16 wide, unpadded; the 16-byte chunks of a row are XOR-swizzled with the index of the 256-byte
+  // group the row sits in, which makes both the 16-byte fragment reads (16 rows per LDS cycle, 64 banks) and the 8-byte
+  // staging stores (128 contiguous bytes per 16 lanes, 32 banks) conflict-free.  (The first version padded rows by 16
+  // bytes: reads were clean but every store was a 2-way conflict, 30 % of the LDS cycles by SQ_LDS_BANK_CONFLICT.)
+  constexpr int RP = 128 / BK, CPR = BK / 8;        // rows per 256 bytes, 16-byte chunks per row
+  auto off = [](int row, int chunk) { return row * BK + ((chunk ^ ((row / RP) & (CPR - 1))) << 3); };
+  constexpr int K4 = BK / 4;                        // float4 per tile row
+  constexpr int RPP = SB_THREADS / K4;              // rows covered by one pass of the workgroup
+  constexpr int A_PER = SB_BM / RPP, B_PER = SB_BN / RPP;
+  static_assert(A_PER >= 1 && B_PER >= 1, "stage shape");
+  __shared__ __attribute__((aligned(16))) __bf16 sA[NS][SB_BM * BK];
+  __shared__ __attribute__((aligned(16))) __bf16 sB[NS][SB_BN * BK];
+
+  int t = xcd_remap(blockIdx.x, p.total);
+  const int tn = t % p.tiles_n; t /= p.tiles_n;     // column tiles of one row panel are XCD neighbours
+  const int tm = t % p.tiles_m;
+  const int bi = t / p.tiles_m;
+  const int m0 = tm * SB_BM, n0 = tn * SB_BN;
+  const float* A = p.a + (size_t)bi * p.a_bs;
+  const float* Bt = p.bt + (size_t)bi * p.bt_bs;
+  float* C = p.c + (size_t)bi * p.c_bs;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int kq = tid % K4, r0 = tid / K4;
+
+  const float* ga[A_PER];
+  const float* gb[B_PER];
+#pragma unroll
+  for (int j = 0; j < A_PER; ++j) ga[j] = A + (size_t)min(m0 + r0 + j * RPP, p.M - 1) * p.lda + kq * 4;
+#pragma unroll
+  for (int j = 0; j < B_PER; ++j) gb[j] = Bt + (size_t)(n0 + r0 + j * RPP) * p.K + kq * 4;   // panel rows are padded
+
+  f32x4 ra[A_PER], rb[B_PER];
+#pragma unroll
+  for (int j = 0; j < A_PER; ++j) ra[j] = *(const f32x4*)ga[j];
+#pragma unroll
+  for (int j = 0; j < B_PER; ++j) rb[j] = *(const f32x4*)gb[j];
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31, fk8 = lane >> 5;
+  const int KT = p.K / BK;
+  for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+      bf16x4 pc[NS];
+      split4<NS>(ra[j], pc);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) *(bf16x4*)&sA[c][off(r0 + j * RPP, kq >> 1) + (kq & 1) * 4] = pc[c];
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+      bf16x4 pc[NS];
+      split4<NS>(rb[j], pc);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) *(bf16x4*)&sB[c][off(r0 + j * RPP, kq >> 1) + (kq & 1) * 4] = pc[c];
+    }
+    __syncthreads();
+    if (kt + 1 < KT) {
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) ra[j] = *(const f32x4*)(ga[j] + (size_t)(kt + 1) * BK);
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) rb[j] = *(const f32x4*)(gb[j] + (size_t)(kt + 1) * BK);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fb[2][NS];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < NS; ++c)
+          fb[j][c] = *(const bf16x8*)&sB[c][off(wn * 64 + j * 32 + frow, ks * 2 + fk8)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 fa[NS];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) fa[c] = *(const bf16x8*)&sA[c][off(wm * 64 + i * 32 + frow, ks * 2 + fk8)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // small terms first, the leading product last
+          if (NS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[j][0], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[j][0], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (col >= p.Nout) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < p.M) C[(size_t)row * p.ldc + col] = acc[i][j][e];
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int semseg_gemm_rows_batched_bf16split(const float* a, int lda, long long a_bs, const float* bt,
+                                                  long long bt_bs, float* c, int ldc, long long c_bs, int M, int K,
+                                                  int Nout, int batch, int nsplit, int bk, hipStream_t stream) {
+  if (!a || !bt || !c || M <= 0 || Nout <= 0 || batch <= 0 || K <= 0) return SEMSEG_EINVAL;
+  if ((nsplit != 2 && nsplit != 3) || (bk != 16 && bk != 32) || K % bk != 0 || (lda & 3) || (K & 3)) return SEMSEG_EINVAL;
+  if (nsplit == 3 && bk != 16) return SEMSEG_EINVAL;      // three pieces at BK 32 would not leave two workgroups per CU
+  SplitArgs p;
+  p.a = a; p.bt = bt; p.c = c;
+  p.a_bs = a_bs; p.bt_bs = bt_bs; p.c_bs = c_bs;
+  p.lda = lda; p.ldc = ldc; p.M = M; p.K = K; p.Nout = Nout;
+  p.tiles_m = (M + SB_BM - 1) / SB_BM;
+  p.tiles_n = (Nout + SB_BN - 1) / SB_BN;
+  p.total = p.tiles_m * p.tiles_n * batch;
+  if (nsplit == 2 && bk == 32) gemm_rows_bf16split_kernel<2, 32><<<p.total, SB_THREADS, 0, stream>>>(p);
+  else if (nsplit == 2) gemm_rows_bf16split_kernel<2, 16><<<p.total, SB_THREADS, 0, stream>>>(p);
+  else gemm_rows_bf16split_kernel<3, 16><<<p.total, SB_THREADS, 0, stream>>>(p);
+  return semseg_launch_status();
+}

@@ -112,12 +112,18 @@ class Act:
 
 WINO_HBM = "wino_input / wino_output / wino_dy_wgrad / wino_filter_grad kernels (Winograd transforms, HBM-bound)"
 WINOGRAD = os.environ.get("SEMSEG_WINOGRAD", "1") != "0"   # 0: every 3x3 conv on the direct implicit-GEMM kernels (A/B)
+# EXPERIMENT, never the reported configuration: 3 | 6 routes the forward and data-gradient row
+# GEMMs of the named Winograd convs through the split-bf16 kernel (csrc/gemm_bf16split.hip; 3 = two pieces / three
+# MFMAs, 6 = three pieces / six MFMAs).  0 = fp32 matrix-core instructions everywhere.
+SPLIT_BF16 = int(os.environ.get("SEMSEG_SPLIT_BF16", "0"))
+SPLIT_LAYERS = os.environ.get("SEMSEG_SPLIT_LAYERS", "cls.0").split(",")
 
 
 class ConvL:
-    def __init__(self, mod, device, need_dgrad=True, training=True):
+    def __init__(self, mod, device, need_dgrad=True, training=True, name=""):
         w = mod.weight
         self.mod = mod
+        self.split = 0
         self.Co, self.Ci, self.R, self.S = w.shape
         self.stride, self.pad, self.dil = mod.stride[0], mod.padding[0], mod.dilation[0]
         # Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convs (csrc/winograd.hip): 1 / 2.25 of the
@@ -132,6 +138,9 @@ class ConvL:
                 and self.Ci % 64 == 0 and self.Ci >= 128 and self.Co % 128 == 0 and mod.bias is None):
             self.wino = ops.WinoConv(self.Co, self.Ci, device, need_dgrad)
             self.pk = None
+            if SPLIT_BF16 and (name in SPLIT_LAYERS or "all" in SPLIT_LAYERS) and self.Ci % 128 == 0:
+                assert SPLIT_BF16 in (3, 6), "SEMSEG_SPLIT_BF16 must be 0, 3 or 6"
+                self.split = SPLIT_BF16
         else:
             self.pk = ops.PackedConv(self.Co, self.Ci, self.R, self.S, device, need_dgrad)
         self.wgrad = None
@@ -289,7 +298,8 @@ class Engine:
                     self.convs[m] = None  # stem: direct kernel, no packed panel
                 else:
                     # eval engines never run a data-gradient: no second packed panel (halves their weight copy)
-                    self.convs[m] = ConvL(m, self.device, need_dgrad=self.training, training=self.training)
+                    self.convs[m] = ConvL(m, self.device, need_dgrad=self.training, training=self.training,
+                                          name=name)
             elif isinstance(m, nn.modules.batchnorm._BatchNorm):
                 self.bns[m] = BNL(m, self)
 
@@ -436,12 +446,12 @@ class Engine:
                 sc, sh, relu, res = fold if fold is not None else (None, None, False, None)
                 self._wino_rows(x.data, x.ld, cl.Ci, cl.wino.U_fwd, cl.wino.Co_pad, out.data, out.ld, cl.Co, x.N, x.H,
                                 x.W, cl.dil, T, self._wino_scratch("Vdy", 16 * T * cl.Ci), add=None if res is None else
-                                res.data, ldadd=0 if res is None else res.ld, fold=(sc, sh, relu))
+                                res.data, ldadd=0 if res is None else res.ld, fold=(sc, sh, relu), split=cl.split)
                 return out
             assert fold is None
             V = self.buf((16 * T * cl.Ci,), tag="winoV")      # kept: the weight gradient contracts it with dy
             self._wino_rows(x.data, x.ld, cl.Ci, cl.wino.U_fwd, cl.wino.Co_pad, out.data, out.ld, cl.Co, x.N, x.H, x.W,
-                            cl.dil, T, V, stats=stats)
+                            cl.dil, T, V, stats=stats, split=cl.split)
             if x.fuse_ok:
                 x.pending += 1
             self.push("conv", lambda: self._conv_bwd_wino(x, out, cl, m, V, T), x=x, y=out, cl=cl, m=m)
@@ -540,7 +550,7 @@ class Engine:
         return t
 
     def _wino_rows(self, src, lds, K, U, rows_pad, dst, ldd, Nout, N, H, W, d, T, V, stats=None, add=None, ldadd=0,
-                   bnr=None, fold=None):
+                   bnr=None, fold=None, split=0):
         """input transform -> 16 batched row GEMMs [T x K] x [K x Nout] -> output transform: the forward of a Winograd conv
         (src = x, U = U_fwd) and its data gradient (src = dy, U = the flipped / transposed filter)."""
         px = N * H * W
@@ -548,9 +558,14 @@ class Engine:
         ev = self._t0(WINO_HBM, -4.0 * (px * K + 16 * T * K))
         ops.wino_input_transform(src, lds, V, N, H, W, K, d)
         self._t1(ev)
-        ev = self._t0("conv_igemm_kernel<128,%d,false,1>(+splitk_epilogue)" % (128 if Nout >= 128 else 64),
-                      2.0 * 16 * T * Nout * K)
-        ops.gemm_rows_batched(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16)
+        if split:
+            ev = self._t0("gemm_rows_bf16split_kernel<%d> (experiment)" % split, 2.0 * 16 * T * Nout * K)
+            ops.gemm_rows_batched_bf16split(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16,
+                                            nsplit=2 if split == 3 else 3)
+        else:
+            ev = self._t0("conv_igemm_kernel<128,%d,false,1>(+splitk_epilogue)" % (128 if Nout >= 128 else 64),
+                          2.0 * 16 * T * Nout * K)
+            ops.gemm_rows_batched(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16)
         self._t1(ev)
         ev = self._t0(WINO_HBM, -4.0 * (16 * T * Nout + px * Nout * (1 + (add is not None) + (2 if bnr else 0))))
         if bnr is not None:
@@ -608,7 +623,7 @@ class Engine:
                 bnr = (x.data if bs["relu"] else None, x.ld, yk.data, yk.ld, blk.mean, blk.invstd, blk.sums)
             self._wino_rows(dy, y.ld, cl.wino.Kc, cl.wino.U_dgrad, cl.wino.Ci_pad, gx, x.ld, cl.Ci, N, H, W, d, T,
                             self._wino_scratch("Vdy", 16 * T * cl.wino.Kc), add=gx if x.ginit else None, ldadd=x.ld,
-                            bnr=bnr)
+                            bnr=bnr, split=cl.split)
             if bnr is not None:
                 x.bn_reduced = True
             x.ginit = True

@@ -522,6 +522,13 @@ def gemm_rows_batched(a, lda, a_bs, bt, bt_bs, c, ldc, c_bs, M, K, Nout, batch):
                                      _stream()), "gemm_rows_batched")
 
 
+def gemm_rows_batched_bf16split(a, lda, a_bs, bt, bt_bs, c, ldc, c_bs, M, K, Nout, batch, nsplit=2, bk=16):
+    """EXPERIMENT: gemm_rows_batched with the fp32 operands split into nsplit bf16 pieces in flight and multiplied on the
+    bf16 matrix-core instruction (csrc/gemm_bf16split.hip).  Bt rows must be readable up to roundup(Nout, 128)."""
+    _ck(lib.semseg_gemm_rows_batched_bf16split(_ptr(a), lda, a_bs, _ptr(bt), bt_bs, _ptr(c), ldc, c_bs, M, K, Nout,
+                                               batch, nsplit, bk, _stream()), "gemm_rows_batched_bf16split")
+
+
 def gemm_kmajor_batched(x, ldx, x_bs, y, ldy, y_bs, out, out_bs, scratch, K, Ci, Co, batch, accumulate=False):
     """out[b][Co][Ci] (=|+=) sum_k y[b][k][co] * x[b][k][ci] in ONE launch of the weight-gradient kernel."""
     _ck(lib.semseg_gemm_kmajor_batched(_ptr(x), ldx, x_bs, _ptr(y), ldy, y_bs, _ptr(out), out_bs, _p(scratch),

@@ -1,6 +1,7 @@
 """GPU parity of every C-ABI kernel against a plain torch CPU reference of the same op (fp64 where a
 tighter reference is useful).  Error metric: max|a-b| / max|b| (relative to the tensor's scale), the
 same normalisation BASELINE.json uses for the logits."""
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -858,3 +859,32 @@ def test_gemm_kmajor_batched_chunks_when_scratch_is_small(report):
     with pytest.raises(ops.HipError):
         ops.gemm_kmajor_batched(x, Ci, K * Ci, y, Co, K * Co, out, Co * Ci, torch.empty(Co * Ci - 1, device=DEV), K, Ci,
                                 Co, B)
+
+
+@pytest.mark.parametrize("nsplit,bk", [(2, 16), (2, 32), (3, 16)])
+def test_gemm_rows_bf16split_experiment(nsplit, bk, report):
+    """EXPERIMENT (off by default): the split-bf16 row GEMM against fp64 and next to the fp32
+    matrix-core kernel on the same operands — ragged last row tile, a column tile that is half padding, strided A and C,
+    batch strides.  Bounds from the error model: three pieces / six products carry 24 mantissa bits (rms within 2x of
+    the fp32 kernel's own rounding noise + 1e-7); two pieces / three products carry 16 (rms <= 1e-5)."""
+    from semseg_amd import ops, engine
+    assert engine.SPLIT_BF16 == int(os.environ.get("SEMSEG_SPLIT_BF16", "0"))     # the flag is opt-in
+    B, M, K, Nout, lda, ldc = 3, 300, 1024, 192, 1024 + 64, 192 + 64
+    g = torch.Generator().manual_seed(17 + nsplit + bk)
+    a = torch.randn(B, M, lda, generator=g)
+    bt = torch.zeros(B, 256, K)                      # panel rows padded to 256, the padding stays zero
+    bt[:, :Nout] = torch.randn(B, Nout, K, generator=g) / K ** 0.5
+    ref = torch.einsum("bmk,bnk->bmn", a[:, :, :K].double(), bt[:, :Nout].double())
+    ad, btd = a.to(DEV), bt.to(DEV)
+    out = torch.full((B, M, ldc), float("nan"), device=DEV)
+    ops.gemm_rows_batched_bf16split(ad, lda, M * lda, btd, 256 * K, out, ldc, M * ldc, M, K, Nout, B, nsplit=nsplit, bk=bk)
+    base = torch.full((B, M, ldc), float("nan"), device=DEV)
+    ops.gemm_rows_batched(ad, lda, M * lda, btd, 256 * K, base, ldc, M * ldc, M, K, Nout, B)
+    torch.cuda.synchronize()
+    assert torch.isnan(out[:, :, Nout:]).all()       # nothing written past Nout
+    rms = lambda t: float((t[:, :, :Nout].cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    e, e32 = rms(out), rms(base)
+    report("gemm_rows_batched_bf16split nsplit %d bk %d: rms %.2e (fp32 matrix-core kernel %.2e)" % (nsplit, bk, e, e32))
+    assert e <= (2.0 * e32 + 1e-7 if nsplit == 3 else 1e-5)
+    with pytest.raises(ops.HipError):
+        ops.gemm_rows_batched_bf16split(ad, lda, M * lda, btd, 256 * K, out, ldc, M * ldc, M, K, Nout, B, nsplit=3, bk=32)
