@@ -102,6 +102,11 @@ int semseg_gemm_kmajor_batched(const float* x, int ldx, long long x_bs, const fl
  * ah*bh + ah*bl + al*bh, ~2^-16 per product; 3: six products, ~2^-23) and multiplied on v_mfma_f32_32x32x16_bf16 with
  * fp32 accumulation.  Same operands and strides; bk = 16 | 32 (32 only with nsplit 2), K % bk == 0, lda % 4 == 0,
  * Bt rows readable up to roundup(Nout, 128). */
+/* EXPERIMENT switch, process-wide, not thread-safe: pieces = 3 makes the 1x1 / GEMM instances of semseg_conv_fwd,
+ * semseg_conv_dgrad (+ fused BatchNorm-backward reduction) and semseg_gemm_rows[_batched] form their products from three-way
+ * split bf16 pieces (six bf16 matrix-core instructions per 16 K, fp32 accumulation, same epilogues); 0 restores the fp32
+ * instructions.  Returns the previous value. */
+int semseg_experiment_conv_split(int pieces);
 int semseg_gemm_rows_batched_bf16split(const float* a, int lda, long long a_bs, const float* bt, long long bt_bs,
                                        float* c, int ldc, long long c_bs, int M, int K, int Nout, int batch, int nsplit,
                                        int bk, hipStream_t stream);

@@ -6,8 +6,9 @@ gpurun_out/split_bf16_probe.json.
      positions x 14400 tiles), standalone: us per launch, TFLOP/s (fp32-equivalent), rms / max error against fp64
   B  PSPNet-101 473x473 eval logits against the CPU oracle with SEMSEG_SPLIT_BF16 = 0 / 3 / 6 (cls.0 only)
   C  in-situ backward check of cls.0 (PSPNet-101 473x473 batch 2): data-gradient error / CPU-fp32 error
-  D  ms per train step (PSPNet-101 473x473 batch 16) with the flag 0 / 3 / 6 on cls.0, and on every Winograd conv
-     (forward + data-gradient GEMMs; the weight-gradient GEMM and the 1x1 convs stay fp32 MFMA)
+  D  ms per train step (PSPNet-101 473x473 batch 16) with the flag 0 / 3 / 6 on cls.0, and on every eligible conv:
+     3 = forward + data-gradient GEMMs of the Winograd convs; 6 = those plus forward / data gradient of every 1x1 conv
+     (SP instances of conv_igemm_kernel); weight gradients always stay fp32 MFMA
 """
 import json
 import os
@@ -50,9 +51,14 @@ def part_a():
         rms_ref = float(ref.pow(2).mean().sqrt())
         flops = 2.0 * batch * T * K * Nout
         rows = {}
-        variants = [("fp32 mfma", None), ("bf16 x3 bk16", (2, 16)), ("bf16 x3 bk32", (2, 32)), ("bf16 x6 bk16", (3, 16))]
+        variants = [("fp32 mfma", None), ("bf16 x3 bk16", (2, 16)), ("bf16 x3 bk32", (2, 32)), ("bf16 x6 bk16", (3, 16)),
+                    ("bf16 x6 igemm SP", "igemm")]
         for name, cfg in variants:
-            if cfg is None:
+            if cfg == "igemm":
+                def fn():
+                    with ops.conv_split(True):
+                        ops.gemm_rows_batched(A, K, T * K, Bt, Nout * K, C, Nout, T * Nout, T, K, Nout, batch)
+            elif cfg is None:
                 fn = lambda: ops.gemm_rows_batched(A, K, T * K, Bt, Nout * K, C, Nout, T * Nout, T, K, Nout, batch)
             else:
                 fn = lambda cfg=cfg: ops.gemm_rows_batched_bf16split(A, K, T * K, Bt, Nout * K, C, Nout, T * Nout, T, K,
@@ -139,9 +145,14 @@ def part_d():
     g = torch.Generator().manual_seed(1000)
     x = torch.randn(16, 3, 473, 473, generator=g).to(DEV)
     y = torch.randint(0, 150, (16, 473, 473), generator=g).to(DEV)
-    for split, layers in ((0, "cls.0"), (3, "cls.0"), (6, "cls.0"), (3, "all"), (6, "all"), (0, "cls.0")):
+    for split, layers, wk, wg in ((0, "cls.0", "standalone", False), (3, "cls.0", "standalone", False),
+                                  (6, "cls.0", "standalone", False), (3, "all", "standalone", False),
+                                  (6, "all", "standalone", False), (6, "all", "igemm", False),
+                                  (6, "all", "standalone", True), (0, "cls.0", "standalone", False)):
         E.SPLIT_BF16 = split
         E.SPLIT_LAYERS = [layers]
+        E.SPLIT_WINO_KERNEL = wk
+        E.SPLIT_WGRAD = wg
         torch.manual_seed(0)
         model = PSPNet(layers=101, classes=150, zoom_factor=8, pretrained=False).to(DEV).train()
         tr = Trainer(model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, aux_weight=0.4, sync_bn=True)
@@ -155,11 +166,15 @@ def part_d():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 8 * 1e3
         lv = [float(l) for l in losses]
-        res.setdefault("%d %s" % (split, layers), []).append(dict(ms=ms, first_loss=lv[0], last_loss=lv[-1]))
-        print("D  SPLIT_BF16=%d layers=%s  %.1f ms/step  loss %.5f -> %.5f" % (split, layers, ms, lv[0], lv[-1]), flush=True)
+        nsp = sum(1 for e in tr.engines.values() for c in e.convs.values() if c is not None and c.split)
+        nw = sum(1 for e in tr.engines.values() for c in e.convs.values() if c is not None and c.split_w)
+        res.setdefault("%d %s %s wgrad=%d" % (split, layers, wk, wg), []).append(
+            dict(ms=ms, loss_after_11_steps=lv[-1], convs_split=nsp, convs_split_wgrad=nw))
+        print("D  SPLIT_BF16=%d layers=%s wino-kernel=%s (%d convs fwd/dgrad, %d wgrad)  %.1f ms/step  loss after 11 steps %.5f"
+              % (split, layers, wk, nsp, nw, ms, lv[-1]), flush=True)
         del tr, model
         torch.cuda.empty_cache()
-    E.SPLIT_BF16, E.SPLIT_LAYERS = 0, ["cls.0"]
+    E.SPLIT_BF16, E.SPLIT_LAYERS, E.SPLIT_WINO_KERNEL, E.SPLIT_WGRAD = 0, ["cls.0"], "standalone", True
     OUT["D_step_ms"] = res
 
 

@@ -329,7 +329,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
 // and the gather uses buffer loads with per-(row,tap) byte offsets precomputed in VGPRs (invalid taps
 // carry an out-of-range offset, which the buffer unit returns as 0) plus one scalar offset per K-step —
 // no per-K-step address VALU between the MFMAs at all.
-template <int BM, int BN, bool TR, int RS_T, bool TL>
+//
+// SP (EXPERIMENT; 0 in every reported configuration): SP = 3 cuts each fp32 operand into three
+// bf16 pieces between the global load and the LDS store and forms the product from six v_mfma_f32_32x32x16_bf16 per
+// 16 K instead of eight v_mfma_f32_32x32x2_f32 — same gather, same accumulators, same epilogues.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+template <int BM, int BN, bool TR, int RS_T, bool TL, int SP = 0>
 __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const ConvArgs pin) {
   ConvArgs p = pin;
   if (p.batch > 1) {
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
   constexpr int RSTEP = NT / 8;              // tile rows staged per pass (8 lanes x 16 B per row)
   constexpr int MREP = 2, NREP = BN / 64;
   constexpr int A_PER = BM / RSTEP, B_PER = BN / RSTEP;
-  constexpr int STAGE = (BM + BN) * LDK;
+  constexpr int STAGE = SP ? SP * (BM + BN) * (BK / 2) : (BM + BN) * LDK;   // SP: bf16 piece planes [piece][row][32]
   constexpr int EPI = (NT / 64) * 64 * LDK;  // per-wave transposition slabs of the epilogue
   constexpr int SMEM_BASE = STAGE > EPI ? STAGE : EPI;
   constexpr int RED2_F = TR ? 2 * (BM / 64) * BN * 2 * 2 : 0;   // fp64 column sums of the fused BatchNorm-backward reduction
@@ -498,17 +505,67 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
     }
   };
 
+  // SP layout: rows of 32 bf16 (64 bytes), the four 16-byte chunks of a row XOR-swizzled with (row / 4) % 4 — the 16-byte
+  // fragment reads (16 rows per LDS cycle) and the 8-byte staging stores (128 contiguous bytes per 16 lanes) are both
+  // conflict-free without padding.  Piece planes: A pieces first, then B pieces.
+  auto sp_off = [](int row, int chunk) { return row * BK + ((chunk ^ ((row >> 2) & 3)) << 3); };
+  auto sp_split_store = [&](__bf16* plane0, int plane_elems, int row, const f32x4 v) {
+    f32x4 r = v;
+#pragma unroll
+    for (int c = 0; c < (SP ? SP : 1); ++c) {
+      const bf16x4 pc = __builtin_convertvector(r, bf16x4);
+      if (c + 1 < SP) r -= __builtin_convertvector(pc, f32x4);
+      *reinterpret_cast<bf16x4*>(&plane0[c * plane_elems + sp_off(row, kq >> 1) + (kq & 1) * 4]) = pc;
+    }
+  };
   auto stage_store = [&](float* A_, float* B_) {
+    if constexpr (SP) {
+      __bf16* Ap = reinterpret_cast<__bf16*>(smem);
+      __bf16* Bp = Ap + SP * BM * BK;
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i)
-      *reinterpret_cast<f32x4*>(&A_[(lrow + RSTEP * i) * LDK + kq * 4]) = ra[i];
+      for (int i = 0; i < A_PER; ++i) sp_split_store(Ap, BM * BK, lrow + RSTEP * i, ra[i]);
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i)
-      *reinterpret_cast<f32x4*>(&B_[(lrow + RSTEP * i) * LDK + kq * 4]) = rb[i];
+      for (int i = 0; i < B_PER; ++i) sp_split_store(Bp, BN * BK, lrow + RSTEP * i, rb[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i)
+        *reinterpret_cast<f32x4*>(&A_[(lrow + RSTEP * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i)
+        *reinterpret_cast<f32x4*>(&B_[(lrow + RSTEP * i) * LDK + kq * 4]) = rb[i];
+    }
   };
   // do_pf: issue the next tile's global loads after the first MFMA group, so their address VALU and
   // issue slots hide in the shadow of this wave's own MFMAs instead of preceding them
   auto compute = [&](const float* A_, const float* B_, auto&& issue_next) {
+    if constexpr (SP) {
+      const __bf16* Ap = reinterpret_cast<const __bf16*>(smem);
+      const __bf16* Bp = Ap + SP * BM * BK;
+#pragma unroll
+      for (int k16 = 0; k16 < 2; ++k16) {
+        bf16x8 a[MREP][SP ? SP : 1], b[NREP][SP ? SP : 1];
+#pragma unroll
+        for (int c = 0; c < SP; ++c) {
+#pragma unroll
+          for (int i = 0; i < MREP; ++i)
+            a[i][c] = *reinterpret_cast<const bf16x8*>(&Ap[c * BM * BK + sp_off(wm * 64 + i * 32 + l31, k16 * 2 + lhi)]);
+#pragma unroll
+          for (int j = 0; j < NREP; ++j)
+            b[j][c] = *reinterpret_cast<const bf16x8*>(&Bp[c * BN * BK + sp_off(wn * (BN / 2) + j * 32 + l31, k16 * 2 + lhi)]);
+        }
+        // small terms first, the leading product last; consecutive MFMAs go to different accumulators
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+        if (k16 == 0) issue_next();
+      }
+      return;
+    }
 #pragma unroll
     for (int k8 = 0; k8 < 4; ++k8) {
       f32x4 a[MREP], b[NREP];
@@ -805,8 +862,13 @@ struct WgradArgs {
 // MODE 0: generic gather (any stride / padding).  MODE 1: 1x1, stride 1, pad 0 — the gathered row IS row m,
 // no decode, always valid.  MODE 2: stride 1 with Ho x Wo == Hin x Win ("same" 3x3, any dilation) — the
 // gathered row is m + tap offset (linear); the pixel is decoded only for the border test.
-template <int TM, int TN, int MODE>
+// SP (EXPERIMENT; 0 in every reported configuration): SP = 3, 128 x 128 only — each thread
+// stages FOUR CONSECUTIVE pixels of its four channels, cuts them into three bf16 pieces and stores them pixel-contiguous
+// ([channel][32 pixels] planes, the layout the bf16 matrix-core instruction wants for a K-major operand), and the
+// product is formed from six v_mfma_f32_32x32x16_bf16 per 16 pixels.
+template <int TM, int TN, int MODE, int SP = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
+  static_assert(SP == 0 || (TM == 128 && TN == 128), "split mode needs 4 float4 per thread and operand");
   WgradArgs p = pin;
   if (p.batch > 1) {
     const long long bz = blockIdx.y;
@@ -818,7 +880,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
   constexpr int YV = TM / 4, XV = TN / 4;          // float4 per k-row
   constexpr int Y_PER = 32 * YV / 256, X_PER = 32 * XV / 256;
   constexpr int YROWS = 256 / YV, XROWS = 256 / XV;  // k-rows covered per pass
-  __shared__ __attribute__((aligned(16))) float smem[32 * (TM + TN)];
+  __shared__ __attribute__((aligned(16))) float smem[SP ? SP * 16 * (TM + TN) : 32 * (TM + TN)];
   float* Ys = smem;            // [32][TM]
   float* Xs = smem + 32 * TM;  // [32][TN]
 
@@ -841,8 +903,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
   const int kbeg = ks * p.kper;
   const int kend = min(p.M, kbeg + p.kper);
 
-  const int yc = tid % YV, yr = tid / YV;
-  const int xc = tid % XV, xr = tid / XV;
+  // SP: the pixel group (4 consecutive pixels) is the fastest thread index, so that the 8 lanes of one channel quad
+  // fill one 64-byte LDS row per store
+  const int yc = SP ? tid >> 3 : tid % YV, yr = SP ? tid & 7 : tid / YV;
+  const int xc = SP ? tid >> 3 : tid % XV, xr = SP ? tid & 7 : tid / XV;
   const int hw = p.Ho * p.Wo;
 
   f32x4 ry[Y_PER], rx[X_PER];
@@ -857,13 +921,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
   auto prefetch_into = [&](int kb, f32x4 (&ry)[Y_PER], f32x4 (&rx)[X_PER]) {
 #pragma unroll
     for (int i = 0; i < Y_PER; ++i) {
-      const int m = kb + yr + i * YROWS;
+      const int m = SP ? kb + yr * Y_PER + i : kb + yr + i * YROWS;
       const float* src = m < kend ? p.dy + (size_t)m * p.lddy + co0 + yc * 4 : g_zero_line;
       ry[i] = *reinterpret_cast<const f32x4*>(src);
     }
 #pragma unroll
     for (int i = 0; i < X_PER; ++i) {
-      const int m = kb + xr + i * XROWS;
+      const int m = SP ? kb + xr * X_PER + i : kb + xr + i * XROWS;
       if constexpr (MODE == 1) {
         const float* src = m < kend ? xlin + (size_t)m * p.ldx : g_zero_line;
         rx[i] = *reinterpret_cast<const f32x4*>(src);
@@ -899,41 +963,87 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
   // WGRAD_ABL (measurement only, results are wrong): 1 = no global loads in the loop, 2 = additionally no
   // LDS stores / barriers per step, 3 = additionally fragments from registers (pure MFMA ceiling)
   if (kbeg < kend) prefetch(kbeg);
-  for (int kb = kbeg; kb < kend; kb += 32) {
+  if constexpr (SP) {
+    __bf16* Yp = reinterpret_cast<__bf16*>(smem);      // [piece][TM channels][32 pixels], 16-byte chunks swizzled
+    __bf16* Xp = Yp + SP * TM * 32;
+    auto sp_off = [](int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); };
+    auto sp_store = [&](__bf16* plane0, int plane_elems, int quad, int pg, const f32x4 (&rr)[4]) {
 #pragma unroll
-    for (int i = 0; i < Y_PER; ++i)
-      *reinterpret_cast<f32x4*>(&Ys[(yr + i * YROWS) * TM + yc * 4]) = ry[i];
+      for (int c = 0; c < 4; ++c) {
+        f32x4 v = {rr[0][c], rr[1][c], rr[2][c], rr[3][c]};     // four consecutive pixels of one channel
 #pragma unroll
-    for (int i = 0; i < X_PER; ++i)
-      *reinterpret_cast<f32x4*>(&Xs[(xr + i * XROWS) * TN + xc * 4]) = rx[i];
-    __syncthreads();
-    // fragments of k-pair kp+1 are read from LDS while the MFMAs of k-pair kp issue (the compiler
-    // otherwise waits for every ds_read right in front of its 4 MFMAs)
-    float fa[2][MREP], fb[2][NREP];
-#pragma unroll
-    for (int i = 0; i < MREP; ++i) fa[0][i] = Ys[(lhi)*TM + wm * (TM / 2) + i * 32 + l31];
-#pragma unroll
-    for (int j = 0; j < NREP; ++j) fb[0][j] = Xs[(lhi)*TN + wn * (TN / 2) + j * 32 + l31];
-#pragma unroll
-    for (int kp = 0; kp < 16; ++kp) {
-      if (kp + 1 < 16) {
-#pragma unroll
-        for (int i = 0; i < MREP; ++i)
-          fa[(kp + 1) & 1][i] = Ys[(2 * (kp + 1) + lhi) * TM + wm * (TM / 2) + i * 32 + l31];
-#pragma unroll
-        for (int j = 0; j < NREP; ++j)
-          fb[(kp + 1) & 1][j] = Xs[(2 * (kp + 1) + lhi) * TN + wn * (TN / 2) + j * 32 + l31];
+        for (int pc = 0; pc < SP; ++pc) {
+          const bf16x4 h = __builtin_convertvector(v, bf16x4);
+          if (pc + 1 < SP) v -= __builtin_convertvector(h, f32x4);
+          *reinterpret_cast<bf16x4*>(&plane0[pc * plane_elems + sp_off(quad * 4 + c, pg >> 1) + (pg & 1) * 4]) = h;
+        }
       }
+    };
+    for (int kb = kbeg; kb < kend; kb += 32) {
+      sp_store(Yp, TM * 32, yc, yr, ry);
+      sp_store(Xp, TN * 32, xc, xr, rx);
+      __syncthreads();
 #pragma unroll
-      for (int i = 0; i < MREP; ++i)
+      for (int k16 = 0; k16 < 2; ++k16) {
+        bf16x8 fa[MREP][SP], fb[NREP][SP];
 #pragma unroll
-        for (int j = 0; j < NREP; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][i], fb[kp & 1][j], acc[i][j], 0, 0, 0);
-      if (kp == 3 && kb + 32 < kend) prefetch(kb + 32);
+        for (int pc = 0; pc < SP; ++pc) {
+#pragma unroll
+          for (int i = 0; i < MREP; ++i)
+            fa[i][pc] = *reinterpret_cast<const bf16x8*>(&Yp[pc * TM * 32 + sp_off(wm * (TM / 2) + i * 32 + l31, k16 * 2 + lhi)]);
+#pragma unroll
+          for (int j = 0; j < NREP; ++j)
+            fb[j][pc] = *reinterpret_cast<const bf16x8*>(&Xp[pc * TN * 32 + sp_off(wn * (TN / 2) + j * 32 + l31, k16 * 2 + lhi)]);
+        }
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[q]], fb[j][PB[q]], acc[i][j], 0, 0, 0);
+        if (k16 == 0 && kb + 32 < kend) prefetch(kb + 32);
+      }
+      __syncthreads();
     }
-    __syncthreads();
-  }
+  } else {
+    for (int kb = kbeg; kb < kend; kb += 32) {
+  #pragma unroll
+      for (int i = 0; i < Y_PER; ++i)
+        *reinterpret_cast<f32x4*>(&Ys[(yr + i * YROWS) * TM + yc * 4]) = ry[i];
+  #pragma unroll
+      for (int i = 0; i < X_PER; ++i)
+        *reinterpret_cast<f32x4*>(&Xs[(xr + i * XROWS) * TN + xc * 4]) = rx[i];
+      __syncthreads();
+      // fragments of k-pair kp+1 are read from LDS while the MFMAs of k-pair kp issue (the compiler
+      // otherwise waits for every ds_read right in front of its 4 MFMAs)
+      float fa[2][MREP], fb[2][NREP];
+  #pragma unroll
+      for (int i = 0; i < MREP; ++i) fa[0][i] = Ys[(lhi)*TM + wm * (TM / 2) + i * 32 + l31];
+  #pragma unroll
+      for (int j = 0; j < NREP; ++j) fb[0][j] = Xs[(lhi)*TN + wn * (TN / 2) + j * 32 + l31];
+  #pragma unroll
+      for (int kp = 0; kp < 16; ++kp) {
+        if (kp + 1 < 16) {
+  #pragma unroll
+          for (int i = 0; i < MREP; ++i)
+            fa[(kp + 1) & 1][i] = Ys[(2 * (kp + 1) + lhi) * TM + wm * (TM / 2) + i * 32 + l31];
+  #pragma unroll
+          for (int j = 0; j < NREP; ++j)
+            fb[(kp + 1) & 1][j] = Xs[(2 * (kp + 1) + lhi) * TN + wn * (TN / 2) + j * 32 + l31];
+        }
+  #pragma unroll
+        for (int i = 0; i < MREP; ++i)
+  #pragma unroll
+          for (int j = 0; j < NREP; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][i], fb[kp & 1][j], acc[i][j], 0, 0, 0);
+        if (kp == 3 && kb + 32 < kend) prefetch(kb + 32);
+      }
+      __syncthreads();
+    }
 
+  }
   float* out = p.dw + (size_t)ks * p.Co_pad * RS * p.Ci;
 #pragma unroll
   for (int i = 0; i < MREP; ++i)
@@ -1326,6 +1436,15 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 // splitting K, so no partial slabs and no separate epilogue pass
 static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064 || t == 1128; }
 
+// EXPERIMENT switch, process-wide and not thread-safe: 3 = the 1x1 / GEMM instances of the forward /
+// data-gradient kernel form their products from three-way split bf16 pieces.  0 (default) everywhere that is reported.
+static int g_conv_split = 0;
+int semseg_experiment_conv_split(int pieces) {
+  const int old = g_conv_split;
+  if (pieces == 0 || pieces == 3) g_conv_split = pieces;
+  return old;
+}
+
 static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, float* scratch,
                        size_t scratch_floats, hipStream_t stream) {
   const int BMr = tile_code >= 1000 ? 64 : 128;
@@ -1407,7 +1526,10 @@ static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, float*
 #define LAUNCH_RS(BM_, BN_, TR_)                                   \
   do {                                                             \
     if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);             \
-    else if (bl) LAUNCH_CONV(BM_, BN_, TR_, 1);                    \
+    else if (bl && g_conv_split == 3) {                            \
+      if (tl) conv_igemm_kernel<BM_, BN_, TR_, 1, true, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);   \
+      else conv_igemm_kernel<BM_, BN_, TR_, 1, false, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);     \
+    } else if (bl) LAUNCH_CONV(BM_, BN_, TR_, 1);                  \
     else LAUNCH_CONV(BM_, BN_, TR_, 0);                            \
   } while (0)
   if (BMr == 128 && BN == 128) {
@@ -1588,7 +1710,8 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
     if (tiles > thr) dma_env = vb;
   }
   const bool dma_ok = (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
-  const int dma = (big && dma_ok && dma_env >= 0 && dma_env <= 7) ? dma_env : 0;
+  const bool sp = big && g_conv_split == 3;      // EXPERIMENT: register-staged 128 x 128 kernel, split-bf16 products
+  const int dma = (big && !sp && dma_ok && dma_env >= 0 && dma_env <= 7) ? dma_env : 0;
   static const int occ_of[8] = {3, 2, 3, 2, 5, 5, 2, 2};
   // Fill whole residency rounds (256 CUs x resident workgroups per CU): among the K splits that give at most two
   // rounds, take the one with the best fill (ties: fewer splits = fewer slabs to write and reduce).
@@ -1628,7 +1751,11 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
     else if (mode == 2) conv_wgrad_dma_kernel<2, KS_, NST_, OCC_, TL_><<<grid, 256, 0, stream>>>(a);    \
     else conv_wgrad_dma_kernel<0, KS_, NST_, OCC_, TL_><<<grid, 256, 0, stream>>>(a);                   \
   } while (0)
-  if (big && dma == 1) LAUNCH_WGRAD_DMA(32, 2, 2, false);
+  if (sp) {
+    if (mode == 1) conv_wgrad_kernel<128, 128, 1, 3><<<grid, 256, 0, stream>>>(a);
+    else if (mode == 2) conv_wgrad_kernel<128, 128, 2, 3><<<grid, 256, 0, stream>>>(a);
+    else conv_wgrad_kernel<128, 128, 0, 3><<<grid, 256, 0, stream>>>(a);
+  } else if (big && dma == 1) LAUNCH_WGRAD_DMA(32, 2, 2, false);
   else if (big && dma == 2) LAUNCH_WGRAD_DMA(16, 3, 3, false);
   else if (big && dma == 3) LAUNCH_WGRAD_DMA(16, 4, 2, false);
   else if (big && dma == 4) LAUNCH_WGRAD_DMA(16, 2, 4, false);

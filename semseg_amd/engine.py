@@ -117,6 +117,11 @@ WINOGRAD = os.environ.get("SEMSEG_WINOGRAD", "1") != "0"   # 0: every 3x3 conv o
 # MFMAs, 6 = three pieces / six MFMAs).  0 = fp32 matrix-core instructions everywhere.
 SPLIT_BF16 = int(os.environ.get("SEMSEG_SPLIT_BF16", "0"))
 SPLIT_LAYERS = os.environ.get("SEMSEG_SPLIT_LAYERS", "cls.0").split(",")
+# with 6: which kernel runs the Winograd row GEMMs — "standalone" (gemm_bf16split.hip) or "igemm" (the SP instances of
+# conv_igemm_kernel, which the 1x1 convs of the named layers use in any case)
+SPLIT_WINO_KERNEL = os.environ.get("SEMSEG_SPLIT_WINO_KERNEL", "standalone")
+# with 6: weight gradients of the named layers with >= 128 x 128 channels on the SP instance of conv_wgrad_kernel too
+SPLIT_WGRAD = os.environ.get("SEMSEG_SPLIT_WGRAD", "1") != "0"
 
 
 class ConvL:
@@ -124,6 +129,7 @@ class ConvL:
         w = mod.weight
         self.mod = mod
         self.split = 0
+        self.split_w = SPLIT_BF16 == 6 and SPLIT_WGRAD and (name in SPLIT_LAYERS or "all" in SPLIT_LAYERS)
         self.Co, self.Ci, self.R, self.S = w.shape
         self.stride, self.pad, self.dil = mod.stride[0], mod.padding[0], mod.dilation[0]
         # Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convs (csrc/winograd.hip): 1 / 2.25 of the
@@ -143,6 +149,8 @@ class ConvL:
                 self.split = SPLIT_BF16
         else:
             self.pk = ops.PackedConv(self.Co, self.Ci, self.R, self.S, device, need_dgrad)
+            if SPLIT_BF16 == 6 and (name in SPLIT_LAYERS or "all" in SPLIT_LAYERS) and self.R == 1 and self.S == 1:
+                self.split = 6      # forward / data gradient on the SP instances of conv_igemm_kernel
         self.wgrad = None
         self.bgrad = None
 
@@ -458,15 +466,16 @@ class Engine:
             return out
         tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld)
         ev = self._t0("conv_igemm_kernel<%d,%d,false,%d>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
-        if fold is not None:
-            sc, sh, relu, res = fold
-            ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                         bias=sh, scale=sc, relu=relu, add=None if res is None else res.data,
-                         ldadd=0 if res is None else res.ld, scratch=self.scratch())
-        else:
-            ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                         bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats,
-                         nslot=ops.NSLOT, scratch=self.scratch())
+        with ops.conv_split(cl.split == 6):
+            if fold is not None:
+                sc, sh, relu, res = fold
+                ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                             bias=sh, scale=sc, relu=relu, add=None if res is None else res.data,
+                             ldadd=0 if res is None else res.ld, scratch=self.scratch())
+            else:
+                ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                             bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats,
+                             nslot=ops.NSLOT, scratch=self.scratch())
         self._t1(ev)
         if self.training:
             if x.fuse_ok:
@@ -480,8 +489,9 @@ class Engine:
         big = cl.Ci % 128 == 0 and cl.Co >= 128
         # 128 x 128 tiles run the direct-to-LDS kernel (conv_igemm.hip: WGRAD_DMA_POLICY), 64 x 64 the register-staged one
         ev = self._t0("conv_wgrad_dma_kernel<128x128>+reduce" if big else "conv_wgrad_kernel<64,64>+reduce", flops)
-        ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
-                       cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil)
+        with ops.conv_split(cl.split_w):
+            ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
+                           cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil)
         self._t1(ev)
         ready = [m.weight]
         if m.bias is not None:
@@ -525,15 +535,16 @@ class Engine:
                     all(yk.ld % 4 == 0 for yk, _ in bs["bns"]))
             tile = ops.chosen_tile("dgrad", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, y.ld, x.ld)
             ev = self._t0("conv_igemm_kernel<%d,%d,true,%d>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), flops)
-            if fuse:
-                ops.conv_dgrad_bnreduce(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                                        x.data if bs["relu"] else None, x.ld,
-                                        [(yk.data, yk.ld, blk.mean, blk.invstd, blk.sums) for yk, blk in bs["bns"]],
-                                        ops.NSLOT, add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
-                x.bn_reduced = True
-            else:
-                ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                               add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
+            with ops.conv_split(cl.split == 6):
+                if fuse:
+                    ops.conv_dgrad_bnreduce(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                                            x.data if bs["relu"] else None, x.ld,
+                                            [(yk.data, yk.ld, blk.mean, blk.invstd, blk.sums) for yk, blk in bs["bns"]],
+                                            ops.NSLOT, add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
+                    x.bn_reduced = True
+                else:
+                    ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                                   add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
             self._t1(ev)
             x.ginit = True
 
@@ -558,7 +569,11 @@ class Engine:
         ev = self._t0(WINO_HBM, -4.0 * (px * K + 16 * T * K))
         ops.wino_input_transform(src, lds, V, N, H, W, K, d)
         self._t1(ev)
-        if split:
+        if split == 6 and SPLIT_WINO_KERNEL == "igemm":
+            ev = self._t0("conv_igemm_kernel<SP=3> (experiment)", 2.0 * 16 * T * Nout * K)
+            with ops.conv_split(True):
+                ops.gemm_rows_batched(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16)
+        elif split:
             ev = self._t0("gemm_rows_bf16split_kernel<%d> (experiment)" % split, 2.0 * 16 * T * Nout * K)
             ops.gemm_rows_batched_bf16split(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16,
                                             nsplit=2 if split == 3 else 3)
@@ -593,7 +608,8 @@ class Engine:
             ops.wino_dy_transform_wgrad(dy, y.ld, Yh, cl.Co, N, H, W, cl.Co, d)
             self._t1(ev)
             ev = self._t0("conv_wgrad_dma_kernel<128x128>+reduce", gflops)
-            ops.gemm_kmajor_batched(V, cl.Ci, T * cl.Ci, Yh, cl.Co, T * cl.Co, dU, cl.Co * cl.Ci, scr, T, cl.Ci, cl.Co, 16)
+            with ops.conv_split(cl.split_w):
+                ops.gemm_kmajor_batched(V, cl.Ci, T * cl.Ci, Yh, cl.Co, T * cl.Co, dU, cl.Co * cl.Ci, scr, T, cl.Ci, cl.Co, 16)
             self._t1(ev)
             ev = self._t0(WINO_HBM, -4.0 * 25 * cl.Co * cl.Ci)
             ops.wino_filter_grad(dU, cl.wgrad, cl.Co, cl.Ci)

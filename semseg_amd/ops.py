@@ -1,6 +1,8 @@
 """Thin tensor-level wrappers over the C ABI (include/semseg_hip.h).  torch is used only for device
 memory and the current HIP stream.  Every wrapper raises on a non-zero return code; nothing here
 computes on the CPU."""
+import contextlib
+
 import torch
 
 from ._lib import lib
@@ -520,6 +522,20 @@ def gemm_rows_batched(a, lda, a_bs, bt, bt_bs, c, ldc, c_bs, M, K, Nout, batch):
     """C[b][M][Nout] = A[b][M][K] * Bt[b][Nout_pad][K]^T in ONE launch (tensors or raw pointers; strides in floats)."""
     _ck(lib.semseg_gemm_rows_batched(_ptr(a), lda, a_bs, _ptr(bt), bt_bs, _ptr(c), ldc, c_bs, M, K, Nout, batch,
                                      _stream()), "gemm_rows_batched")
+
+
+@contextlib.contextmanager
+def conv_split(on):
+    """EXPERIMENT: inside the block the 1x1 / GEMM instances of conv_fwd, conv_dgrad(_bnreduce) and
+    gemm_rows(_batched) form their products from three-way split bf16 pieces (process-wide host switch, read at launch)."""
+    if not on:
+        yield
+        return
+    old = int(lib.semseg_experiment_conv_split(3))
+    try:
+        yield
+    finally:
+        lib.semseg_experiment_conv_split(old)
 
 
 def gemm_rows_batched_bf16split(a, lda, a_bs, bt, bt_bs, c, ldc, c_bs, M, K, Nout, batch, nsplit=2, bk=16):

@@ -888,3 +888,73 @@ def test_gemm_rows_bf16split_experiment(nsplit, bk, report):
     assert e <= (2.0 * e32 + 1e-7 if nsplit == 3 else 1e-5)
     with pytest.raises(ops.HipError):
         ops.gemm_rows_batched_bf16split(ad, lda, M * lda, btd, 256 * K, out, ldc, M * ldc, M, K, Nout, B, nsplit=3, bk=32)
+
+
+@pytest.mark.parametrize("code", [128, 64, 1128, 1064])
+def test_conv_split_mode_1x1_experiment(code, report, monkeypatch):
+    """EXPERIMENT: the SP instances of the forward / data-gradient kernel (three-way split bf16
+    pieces, six bf16 matrix-core products) on a 1x1 conv with every fused epilogue — forward with batch statistics, data
+    gradient with residual add, data gradient with the fused BatchNorm-backward reduction — next to the fp32 instances
+    on the same operands: rms error within 2x of the fp32 kernel's (+1e-7), statistics and reduction sums to 1e-6."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co = 3, 17, 15, 1024, 256
+    g = torch.Generator().manual_seed(23)
+    x = torch.relu(torch.randn(N, Ci, H, W, generator=g))
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    dy = torch.randn(N, Co, H, W, generator=g)
+    add = torch.randn(N, Ci, H, W, generator=g)
+    y64 = F.conv2d(x.double(), w.double())
+    dx64 = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double()) + add.double()
+    pk = ops.PackedConv(Co, Ci, 1, 1, DEV)
+    pk.pack(w.to(DEV))
+    monkeypatch.setitem(ops.TILE_CHOICE, ops.tile_key("fwd", N, H, W, Ci, Co, 1, 1, 1, 0, 1), code)
+    monkeypatch.setitem(ops.TILE_CHOICE, ops.tile_key("dgrad", N, H, W, Ci, Co, 1, 1, 1, 0, 1), code)
+    xd, dyd, addd = nhwc(x).contiguous().to(DEV), nhwc(dy).contiguous().to(DEV), nhwc(add).contiguous().to(DEV)
+    rms = lambda a, ref: float((a.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    res = {}
+    for split in (False, True):
+        with ops.conv_split(split):
+            yb = torch.empty(N, H, W, Co, device=DEV)
+            stats = torch.zeros(ops.NSLOT * 2 * Co, dtype=torch.float64, device=DEV)
+            ops.conv_fwd(xd, Ci, pk, yb, Co, N, H, W, 1, 0, 1, stats=stats, nslot=ops.NSLOT,
+                         scratch=torch.empty(1 << 24, device=DEV))
+            dxb = torch.empty(N, H, W, Ci, device=DEV)
+            ops.conv_dgrad(dyd, Co, pk, dxb, Ci, N, H, W, 1, 0, 1, add=addd, ldadd=Ci, scratch=torch.empty(1 << 24, device=DEV))
+        torch.cuda.synchronize()
+        st = stats.view(ops.NSLOT, 2 * Co).sum(0).cpu()
+        res[split] = (rms(nchw(yb).cpu(), y64), rms(nchw(dxb).cpu(), dx64),
+                      float((st[:Co] - y64.sum((0, 2, 3))).abs().max() / y64.sum((0, 2, 3)).abs().max()),
+                      float((st[Co:] - (y64 ** 2).sum((0, 2, 3))).abs().max() / (y64 ** 2).sum((0, 2, 3)).abs().max()))
+    report("conv split mode tile %d: forward rms %.2e (fp32 %.2e)  data gradient %.2e (fp32 %.2e)  stats %.1e / %.1e"
+           % (code, res[True][0], res[False][0], res[True][1], res[False][1], res[True][2], res[True][3]))
+    assert res[True][0] <= 2 * res[False][0] + 1e-7 and res[True][1] <= 2 * res[False][1] + 1e-7
+    assert res[True][2] < 1e-6 and res[True][3] < 1e-6
+    assert int(ops.lib.semseg_experiment_conv_split(0)) == 0      # the context manager restored the switch
+
+
+@pytest.mark.parametrize("case", [(2, 23, 21, 256, 128, 1, 1, 0, 1), (2, 19, 17, 128, 256, 3, 1, 2, 2), (2, 21, 21, 256, 256, 1, 2, 0, 1),
+                                  (1, 33, 33, 128, 128, 3, 1, 1, 1)])
+def test_conv_wgrad_split_mode_experiment(case, report, monkeypatch):
+    """EXPERIMENT: the SP instance of the 128 x 128 weight-gradient kernel (pixel-contiguous bf16
+    piece planes, six bf16 matrix-core products) in its three gather modes (1x1, "same" 3x3 with dilation, strided)
+    next to the fp32 kernels on the same operands, against fp64: rms within 2x of the fp32 path's (+1e-7)."""
+    from semseg_amd import ops
+    monkeypatch.setenv("SEMSEG_WGRAD_SMALL", "0")          # keep the 128 x 128 path on these small grids
+    N, H, W, Ci, Co, k, s_, p_, d = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.relu(torch.randn(N, Ci, H, W, generator=g))
+    Ho, Wo = ops.conv_out(H, k, s_, p_, d), ops.conv_out(W, k, s_, p_, d)
+    dy = torch.randn(N, Co, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, k, k), dy.double(), stride=s_, padding=p_, dilation=d)
+    xd, dyd = nhwc(x).contiguous().to(DEV), nhwc(dy).contiguous().to(DEV)
+    scratch = torch.empty(1 << 25, device=DEV)
+    rms = lambda a: float((a.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    errs = []
+    for split in (False, True):
+        dw = torch.full((Co, Ci, k, k), float("nan"), device=DEV)
+        with ops.conv_split(split):
+            ops.conv_wgrad(xd, Ci, dyd, Co, dw, scratch, N, H, W, Ci, Co, k, k, s_, p_, d)
+        torch.cuda.synchronize()
+        errs.append(rms(dw))
+    report("conv_wgrad split mode %s: rms %.2e (fp32 path %.2e)" % (case, errs[1], errs[0]))
+    assert errs[1] <= 2 * errs[0] + 1e-7
