@@ -10,9 +10,9 @@ def family(k):
     """Template instantiations that bench.py's KernelTimer reports as one family: the weight-gradient kernel's
     addressing MODE and the forward/data-gradient kernel's two-level-accumulation flag are dropped."""
     if k.startswith('conv_wgrad_dma_kernel<'): return 'conv_wgrad_dma_kernel<128x128>'
-    m = re.match(r'conv_wgrad_kernel<(\d+), (\d+), \d+>', k)
+    m = re.match(r'conv_wgrad_kernel<(\d+), (\d+), \d+(, 0)?>', k)
     if m: return 'conv_wgrad_kernel<%s, %s>' % (m.group(1), m.group(2))
-    m = re.match(r'conv_igemm_kernel<(\d+), (\d+), (true|false), (\d+), (true|false)>', k)
+    m = re.match(r'conv_igemm_kernel<(\d+), (\d+), (true|false), (\d+), (true|false)(, 0)?>', k)
     if m: return 'conv_igemm_kernel<%s, %s, %s, %s>' % m.groups()[:4]
     return k
 def agg(path):
