@@ -966,7 +966,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
   if constexpr (SP) {
     __bf16* Yp = reinterpret_cast<__bf16*>(smem);      // [piece][TM channels][32 pixels], 16-byte chunks swizzled
     __bf16* Xp = Yp + SP * TM * 32;
-    auto sp_off = [](int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); };
+    // rows of odd channel quads are stored pairwise swapped (row ^ 1): the 16 lanes of one 8-byte store cycle write the
+    // same channel of two neighbouring quads, and without the swap both rows start on the same 16 of the 32 store banks
+    auto sp_off = [](int row, int chunk) {
+      const int pr = row ^ ((row >> 2) & 1);
+      return pr * 32 + ((chunk ^ ((pr >> 2) & 3)) << 3);
+    };
     auto sp_store = [&](__bf16* plane0, int plane_elems, int quad, int pg, const f32x4 (&rr)[4]) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
