@@ -216,7 +216,7 @@ def module_path_step_time(args, dev, world, rank, B, steps, warmup):
     return dt / steps, loss_val
 
 
-def split_bf16_experiment(args, dev, B, steps=6, warmup=2):
+def split_bf16_experiment(args, dev, B, layers, steps=6, warmup=2):
     """NOT the reported configuration: the same Trainer step with every 1x1 conv (forward, data
     gradient), every Winograd GEMM and every 128 x 128 weight gradient formed from six bf16 matrix-core products of
     three-way split fp32 operands with fp32 accumulation (in-situ error no worse than the fp32 matrix-core kernels').
@@ -224,7 +224,7 @@ def split_bf16_experiment(args, dev, B, steps=6, warmup=2):
     from semseg_amd.trainer import Trainer
     from semseg_amd import engine as E
     old = (E.SPLIT_BF16, E.SPLIT_LAYERS, E.SPLIT_WGRAD)
-    E.SPLIT_BF16, E.SPLIT_LAYERS, E.SPLIT_WGRAD = 6, ["all"], True
+    E.SPLIT_BF16, E.SPLIT_LAYERS, E.SPLIT_WGRAD = 6, [layers], True
     try:
         torch.manual_seed(0)
         if args.arch == "psp":
@@ -252,12 +252,8 @@ def split_bf16_experiment(args, dev, B, steps=6, warmup=2):
         torch.cuda.empty_cache()
     finally:
         E.SPLIT_BF16, E.SPLIT_LAYERS, E.SPLIT_WGRAD = old
-    return {"what": "EXPERIMENT, not the reported configuration and not part of `value`: SEMSEG_SPLIT_BF16=6 "
-                    "SEMSEG_SPLIT_LAYERS=all - 1x1 convs (forward, data gradient), Winograd GEMMs and 128x128 weight "
-                    "gradients as six bf16 matrix-core products of three-way split fp32 operands, fp32 accumulation; "
-                    "every in-situ criterion unchanged and green (DESIGN.md section 8.4)",
-            "ms_per_step": round(sec * 1e3, 3), "images_per_sec": round(B / sec, 3), "steps": steps,
-            "convs_on_split_kernel": nsplit, "final_main_loss": round(loss, 5)}
+    return {"layers": layers, "ms_per_step": round(sec * 1e3, 3), "images_per_sec": round(B / sec, 3), "steps": steps,
+            "convs_on_split_kernels": nsplit, "final_main_loss": round(loss, 5)}
 
 
 def main():
@@ -390,7 +386,15 @@ def main():
     experiment = None
     if world == 1 and not args.no_experiments:
         try:
-            experiment = split_bf16_experiment(args, dev, B)
+            experiment = {
+                "what": "EXPERIMENT (review item 7), not the reported configuration and not part of `value`: "
+                        "SEMSEG_SPLIT_BF16=6 - fp32 operands cut into three bf16 pieces in flight, six cross products on "
+                        "the bf16 matrix-core instruction, fp32 accumulation; cls.0 only, and every eligible conv (1x1 "
+                        "forward / data gradient, Winograd GEMMs, 128x128 weight gradients); every parity criterion "
+                        "unchanged and green with it (DESIGN.md section 8.4, profiles/r03_insitu_split_bf16x6.txt)",
+                "dtype": "f32 via 3xbf16 split (6 cross products, fp32 accumulate)",
+                "cls0_only": split_bf16_experiment(args, dev, B, "cls.0"),
+                "all_eligible_convs": split_bf16_experiment(args, dev, B, "all")}
         except Exception as e:                       # a side measurement never takes the bench line down
             experiment = {"error": repr(e)}
 
