@@ -1441,8 +1441,8 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 // splitting K, so no partial slabs and no separate epilogue pass
 static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064 || t == 1128; }
 
-// EXPERIMENT switch, process-wide and not thread-safe: 3 = the 1x1 / GEMM instances of the forward /
-// data-gradient kernel form their products from three-way split bf16 pieces.  0 (default) everywhere that is reported.
+// EXPERIMENT switch, process-wide and not thread-safe: 3 = the 1x1 / GEMM and 3x3 instances of the
+// forward / data-gradient kernel form their products from three-way split bf16 pieces.  0 (default) everywhere that is reported.
 static int g_conv_split = 0;
 int semseg_experiment_conv_split(int pieces) {
   const int old = g_conv_split;
@@ -1530,7 +1530,10 @@ static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, float*
   } while (0)
 #define LAUNCH_RS(BM_, BN_, TR_)                                   \
   do {                                                             \
-    if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);             \
+    if (bl && RSv == 9 && g_conv_split == 3) {                     \
+      if (tl) conv_igemm_kernel<BM_, BN_, TR_, 9, true, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);   \
+      else conv_igemm_kernel<BM_, BN_, TR_, 9, false, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);     \
+    } else if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);      \
     else if (bl && g_conv_split == 3) {                            \
       if (tl) conv_igemm_kernel<BM_, BN_, TR_, 1, true, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);   \
       else conv_igemm_kernel<BM_, BN_, TR_, 1, false, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);     \

@@ -149,7 +149,7 @@ class ConvL:
                 self.split = SPLIT_BF16
         else:
             self.pk = ops.PackedConv(self.Co, self.Ci, self.R, self.S, device, need_dgrad)
-            if SPLIT_BF16 == 6 and (name in SPLIT_LAYERS or "all" in SPLIT_LAYERS) and self.R == 1 and self.S == 1:
+            if SPLIT_BF16 == 6 and (name in SPLIT_LAYERS or "all" in SPLIT_LAYERS) and self.R * self.S in (1, 9):
                 self.split = 6      # forward / data gradient on the SP instances of conv_igemm_kernel
         self.wgrad = None
         self.bgrad = None

@@ -958,3 +958,34 @@ def test_conv_wgrad_split_mode_experiment(case, report, monkeypatch):
         errs.append(rms(dw))
     report("conv_wgrad split mode %s: rms %.2e (fp32 path %.2e)" % (case, errs[1], errs[0]))
     assert errs[1] <= 2 * errs[0] + 1e-7
+
+
+@pytest.mark.parametrize("case", [(3, 13, 11, 128, 128, 3, 1, 2, 2), (2, 21, 21, 128, 256, 3, 2, 1, 1)])
+def test_conv_split_mode_3x3_experiment(case, report):
+    """EXPERIMENT: the SP instances of the 3x3 (unrolled-tap) forward / data-gradient kernel, dilated
+    and strided, next to the fp32 instances against fp64: rms within 2x (+1e-7)."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co, k, s_, p_, d = case
+    g = torch.Generator().manual_seed(41)
+    x = torch.relu(torch.randn(N, Ci, H, W, generator=g))
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    y64 = F.conv2d(x.double(), w.double(), None, s_, p_, d)
+    Ho, Wo = y64.shape[2:]
+    dy = torch.randn(N, Co, Ho, Wo, generator=g)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), stride=s_, padding=p_, dilation=d)
+    pk = ops.PackedConv(Co, Ci, k, k, DEV)
+    pk.pack(w.to(DEV))
+    xd, dyd = nhwc(x).contiguous().to(DEV), nhwc(dy).contiguous().to(DEV)
+    rms = lambda a, ref: float((a.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    res = {}
+    for split in (False, True):
+        with ops.conv_split(split):
+            yb = torch.empty(N, Ho, Wo, Co, device=DEV)
+            ops.conv_fwd(xd, Ci, pk, yb, Co, N, H, W, s_, p_, d, scratch=torch.empty(1 << 24, device=DEV))
+            dxb = torch.empty(N, H, W, Ci, device=DEV)
+            ops.conv_dgrad(dyd, Co, pk, dxb, Ci, N, H, W, s_, p_, d, scratch=torch.empty(1 << 24, device=DEV))
+        torch.cuda.synchronize()
+        res[split] = (rms(nchw(yb).cpu(), y64), rms(nchw(dxb).cpu(), dx64))
+    report("conv 3x3 split mode %s: forward rms %.2e (fp32 %.2e)  data gradient %.2e (fp32 %.2e)"
+           % (case, res[True][0], res[False][0], res[True][1], res[False][1]))
+    assert res[True][0] <= 2 * res[False][0] + 1e-7 and res[True][1] <= 2 * res[False][1] + 1e-7
