@@ -4,6 +4,8 @@ time the four tile shapes (128 x 128, 128 x 64, 64 x 128, 64 x 64) on real opera
 interleaved rounds of 3 launches, device idle) and keep 128 x 128 unless another shape wins by >= 3 %.  The table is committed; nothing times tiles at run time.
 
     SEMSEG_TILE_TUNE=1 python scripts/make_tile_table.py [out.json]        (GPU box; copy the result into semseg_amd/)
+    ... make_tile_table.py --split [out.json]   the same for the split-bf16 experiment's kernel instances (keys "...|sp",
+                                                semseg_amd/tile_table_sp.json; PSPNet-101 473^2 bs 16 / 2 and PSANet-101 bs 16)
 """
 import json
 import os
@@ -20,8 +22,17 @@ CONFIGS = [("psp", 101, 473, 150, b) for b in (16, 8, 4, 2)] + [("psa", 101, 465
           [("psp", 101, 713, 19, 2)]
 
 if __name__ == "__main__":
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "tile_table.json")
-    ops.TILE_CHOICE.clear()      # measure everything afresh
+    args = [a for a in sys.argv[1:] if a != "--split"]
+    SPLIT = "--split" in sys.argv[1:]
+    out = args[0] if args else os.path.join(ROOT, "gpurun_out", "tile_table_sp.json" if SPLIT else "tile_table.json")
+    if SPLIT:
+        from semseg_amd import engine as E
+        E.SPLIT_BF16, E.SPLIT_LAYERS = 6, ["all"]
+        CONFIGS = [("psp", 101, 473, 150, 16), ("psp", 101, 473, 150, 2), ("psa", 101, 465, 150, 16)]
+        for k in [k for k in ops.TILE_CHOICE if k.endswith("|sp")]:
+            del ops.TILE_CHOICE[k]
+    else:
+        ops.TILE_CHOICE.clear()      # measure everything afresh
     for arch, layers, size, classes, bs in CONFIGS:
         torch.manual_seed(0)
         if arch == "psp":
@@ -40,7 +51,7 @@ if __name__ == "__main__":
         print("%s%d %d^2 bs %d: %d new shapes" % (arch, layers, size, bs, len(ops.TILE_CHOICE) - n0), flush=True)
         del tr, m, x, y
         torch.cuda.empty_cache()
-    tiles = dict(sorted(ops.TILE_CHOICE.items()))
+    tiles = dict(sorted((k, v) for k, v in ops.TILE_CHOICE.items() if k.endswith("|sp") == SPLIT))
     doc = {"generated_by": "scripts/make_tile_table.py (3 x 3 launches per tile shape; 128 x 128 unless another wins by >= 3 %)",
            "tile_codes": "128 = 128x128, 64 = 128x64, 1128 = 64x128, 1064 = 64x64 (rows x columns)",
            "configs": ["%s%d_%d_c%d_bs%d" % c for c in CONFIGS],

@@ -99,12 +99,19 @@ def load_tile_table(path=TILE_TABLE_PATH):
 
 
 TILE_CHOICE = load_tile_table()
+# EXPERIMENT: tile shapes measured with the split-bf16 instances of the kernel, keys suffixed "|sp";
+# looked up only inside ops.conv_split(True)
+TILE_TABLE_SP_PATH = TILE_TABLE_PATH.replace("tile_table.json", "tile_table_sp.json")
+TILE_CHOICE.update(load_tile_table(TILE_TABLE_SP_PATH))
+_SPLIT_ON = False
 
 
 def _tuned_tile(key, dflt, device, out_floats, launch):
     codes = TILE_CODES if dflt == 128 else (64, 1064)
     """Table lookup; with SEMSEG_TILE_TUNE=1 an unknown shape is timed once (launch(tile, out_tensor) -> return code of a
     side-effect-free launch of this shape into a scratch output on the operands' device)."""
+    if _SPLIT_ON:
+        key = key + "|sp"
     t = TILE_CHOICE.get(key)
     if t is not None:
         return t
@@ -531,10 +538,13 @@ def conv_split(on):
     if not on:
         yield
         return
+    global _SPLIT_ON
     old = int(lib.semseg_experiment_conv_split(3))
+    was, _SPLIT_ON = _SPLIT_ON, True
     try:
         yield
     finally:
+        _SPLIT_ON = was
         lib.semseg_experiment_conv_split(old)
 
 
