@@ -907,8 +907,9 @@ def test_conv_split_mode_1x1_experiment(code, report, monkeypatch):
     dx64 = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double()) + add.double()
     pk = ops.PackedConv(Co, Ci, 1, 1, DEV)
     pk.pack(w.to(DEV))
-    monkeypatch.setitem(ops.TILE_CHOICE, ops.tile_key("fwd", N, H, W, Ci, Co, 1, 1, 1, 0, 1), code)
-    monkeypatch.setitem(ops.TILE_CHOICE, ops.tile_key("dgrad", N, H, W, Ci, Co, 1, 1, 1, 0, 1), code)
+    for sfx in ("", "|sp"):          # the split instances look their tile up under the suffixed key
+        monkeypatch.setitem(ops.TILE_CHOICE, ops.tile_key("fwd", N, H, W, Ci, Co, 1, 1, 1, 0, 1) + sfx, code)
+        monkeypatch.setitem(ops.TILE_CHOICE, ops.tile_key("dgrad", N, H, W, Ci, Co, 1, 1, 1, 0, 1) + sfx, code)
     xd, dyd, addd = nhwc(x).contiguous().to(DEV), nhwc(dy).contiguous().to(DEV), nhwc(add).contiguous().to(DEV)
     rms = lambda a, ref: float((a.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     res = {}
