@@ -2,6 +2,10 @@
 """bench.py — images/sec of the PSPNet-101 train step (473x473, global batch 16, 150 classes, fp32)
 on N MI355X GPUs of one node, the metric BASELINE.json names.
 
+Arithmetic: fp32 tensors everywhere; the conv GEMMs form their fp32 products per launch either from three-way split
+bf16 pieces (SEMSEG_ARITH_BF16X3, the default: `value`, `dtype` says so) or on the fp32 matrix-core instruction
+(SEMSEG_ARITH_F32: the `exact_fp32` object of the same JSON line, same protocol, same step count).
+
 One "step" = the loop body of the reference's tool/train.py:269-276 on a synthetic batch that is
 already resident in HBM: forward (SyncBN), loss = main + 0.4*aux, backward, gradient all-reduce
 (N>1), SGD(momentum 0.9, wd 1e-4, two lr groups).  Launch for N>1:
@@ -24,7 +28,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 ISO_STEPS = 2
-PMC_FILE = "r03_pmc_per_kernel.json"   # per-kernel HBM bytes / MFMA-busy from the rocprofv3 --pmc passes of this round
+PMC_FILE = "r04_pmc_per_kernel.json"   # per-kernel HBM bytes / MFMA-busy from the rocprofv3 --pmc passes of this round
 
 
 def conv_flops_per_image(model, size):
@@ -216,44 +220,99 @@ def module_path_step_time(args, dev, world, rank, B, steps, warmup):
     return dt / steps, loss_val
 
 
-def split_bf16_experiment(args, dev, B, layers, steps=6, warmup=2):
-    """NOT the reported configuration: the same Trainer step with every 1x1 conv (forward, data
-    gradient), every Winograd GEMM and every 128 x 128 weight gradient formed from six bf16 matrix-core products of
-    three-way split fp32 operands with fp32 accumulation (in-situ error no worse than the fp32 matrix-core kernels').
-    The direct 3x3 / stem convs and everything that is not a GEMM stay as they are.  Single GPU only."""
-    from semseg_amd.trainer import Trainer
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: v_mfma_f32_32x32x16_bf16, dense
+# SEMSEG_ARITH_BF16X3 spends six bf16 matrix-core products per fp32 product: the peak of a bf16x3 kernel in fp32-equivalent
+# FLOPs is the dense bf16 peak / 6 ("no quoting 197 TF against 157.3")
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def family_peak(family):
+    """Matrix-core peak (fp32-equivalent TFLOP/s) of a kernel family by the arithmetic its label names."""
+    return PEAK_BF16X3_TFLOPS if ("SP3" in family or "bf16x3" in family) else PEAK_F32_MFMA_TFLOPS
+
+
+def build_model(args):
+    torch.manual_seed(0)  # identical initial weights on every rank (what DDP's broadcast achieves)
+    if args.arch == "psp":
+        from model.pspnet import PSPNet
+        return PSPNet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
+    from model.psanet import PSANet
+    return PSANet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
+
+
+def trainer_leg(args, dev, world, rank, B, steps, warmup, arith, kernel_timing, dist_on):
+    """`steps` timed Trainer steps (barrier + synchronize on both sides, max over ranks) with the conv GEMMs in `arith`
+    ("bf16x3" | "f32"), then — with kernel_timing — ISO_STEPS more steps with every kernel on ONE stream for the per-family
+    HIP-event durations the roofline uses.  Returns a dict; the Trainer and its engine are released before returning."""
+    from semseg_amd.trainer import Trainer, poly_learning_rate
     from semseg_amd import engine as E
-    old = (E.SPLIT_BF16, E.SPLIT_LAYERS, E.SPLIT_WGRAD)
-    E.SPLIT_BF16, E.SPLIT_LAYERS, E.SPLIT_WGRAD = 6, [layers], True
+    old = E.set_arith(arith)
     try:
-        torch.manual_seed(0)
-        if args.arch == "psp":
-            from model.pspnet import PSPNet
-            model = PSPNet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
-        else:
-            from model.psanet import PSANet
-            model = PSANet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
-        model = model.to(dev).train()
+        model = build_model(args).to(dev).train()
         tr = Trainer(model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, aux_weight=0.4, sync_bn=True)
-        g = torch.Generator().manual_seed(1000)
+        g = torch.Generator().manual_seed(1000 + rank)
         x = torch.randn(B, 3, args.size, args.size, generator=g).to(dev)
         y = torch.randint(0, args.classes, (B, args.size, args.size), generator=g).to(dev)
+        max_iter = steps + warmup + 1 + ISO_STEPS
+        it = 0
         for _ in range(warmup):
-            tr.step(x, y, 0.01)
-        nsplit = sum(1 for e in tr.engines.values() for c in e.convs.values() if c is not None and (c.split or c.split_w))
+            tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
+            it += 1
+        kt = None
+        if rank == 0 and kernel_timing:
+            kt = E.KernelTimer()
+            for e in tr.engines.values():
+                e.ktimer = kt
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(steps):
-            ml = tr.step(x, y, 0.01)[1]
+            _, main_loss, aux_loss = tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
+            it += 1
         torch.cuda.synchronize()
-        sec = (time.time() - t0) / steps
-        loss = float(ml.item())
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        if dist_on:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out = {"sec": dt / steps, "loss": float(main_loss.item()), "arith": arith}
+        for e in tr.engines.values():
+            e.check_labels()
+            out["n_sync"] = getattr(e, "syncbn_collectives_per_step", None)
+            out["two_stream_backward"] = bool(e.side_wgrad)
+            out["convs_bf16x3"] = sum(1 for c in e.convs.values() if c is not None and c.arith == 3)
+        # Serialized leg (every rank runs it: the steps contain the SyncBN / gradient collectives): ISO_STEPS more steps
+        # with all kernels on one stream, HIP-event timed on rank 0 -> per-kernel rates that are not inflated by the
+        # side-stream concurrency of the timed region.
+        if kernel_timing:
+            kt_iso = E.KernelTimer() if rank == 0 else None
+            saved = [(e, e.side_wgrad, e.hipri_main) for e in tr.engines.values()]
+            for e, _, _ in saved:
+                e.side_wgrad, e.hipri_main, e.ktimer = False, False, kt_iso
+            for _ in range(ISO_STEPS):
+                tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
+            torch.cuda.synchronize()
+            for e, sw, hp in saved:
+                e.side_wgrad, e.hipri_main, e.ktimer = sw, hp, None
+            if rank == 0:
+                out["exec_flops"] = kt_iso.mfma_flops() / ISO_STEPS
+                out["kernel_families"] = kt_iso.summary()
+                out["kernel_families_in_step"] = kt.summary()
+                fam = kt_iso.dominant_family()
+                roof = kt_iso.roofline(family_peak(fam), family=fam)
+                ins = kt.roofline(family_peak(fam), family=fam)
+                roof["in_step"] = {k: ins[k] for k in ("achieved", "frac", "avg_launch_us", "launches")}
+                out["roofline"] = roof
         del tr, model
         torch.cuda.empty_cache()
     finally:
-        E.SPLIT_BF16, E.SPLIT_LAYERS, E.SPLIT_WGRAD = old
-    return {"layers": layers, "ms_per_step": round(sec * 1e3, 3), "images_per_sec": round(B / sec, 3), "steps": steps,
-            "convs_on_split_kernels": nsplit, "final_main_loss": round(loss, 5)}
+        E.set_arith(old)
+    return out
 
 
 def main():
@@ -268,7 +327,10 @@ def main():
     ap.add_argument("--arch", default="psp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-experiments", action="store_true", help="skip the labelled split-bf16 side measurement")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 leg reported beside the value")
+    ap.add_argument("--no-experiments", dest="no_exact", action="store_true", help=argparse.SUPPRESS)   # round-3 spelling
+    ap.add_argument("--arith", default=None, choices=["bf16x3", "f32"],
+                    help="arithmetic of the headline leg (default: the engine default, bf16x3 unless SEMSEG_ARITH says f32)")
     ap.add_argument("--path", default="trainer", choices=["trainer", "module"],
                     help="trainer: the fused loop body (semseg_amd.Trainer) is the timed value and the drop-in nn.Module "
                          "+ torch.optim.SGD loop is timed beside it (module_path); module: the other way round")
@@ -279,7 +341,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("SEMSEG_FORCE_DIST") == "1" and "RANK" in os.environ
-    if world > 1 or force_dist:
+    dist_on = world > 1 or force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -291,123 +354,61 @@ def main():
     assert args.global_batch % world == 0
     B = args.global_batch // world
 
-    from semseg_amd.trainer import Trainer, poly_learning_rate
     from semseg_amd import engine as E
-    torch.manual_seed(0)  # identical initial weights on every rank (what DDP's broadcast achieves)
-    if args.arch == "psp":
-        from model.pspnet import PSPNet
-        model = PSPNet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
-    else:
-        from model.psanet import PSANet
-        model = PSANet(layers=args.layers, classes=args.classes, zoom_factor=8, pretrained=False)
-    fwd_flops, first_flops = conv_flops_per_image(model, args.size)
-    model = model.to(dev).train()
-    tr = Trainer(model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, aux_weight=0.4, sync_bn=True)
-
-    g = torch.Generator().manual_seed(1000 + rank)
-    x = torch.randn(B, 3, args.size, args.size, generator=g).to(dev)
-    y = torch.randint(0, args.classes, (B, args.size, args.size), generator=g).to(dev)
+    if args.arith is not None:
+        E.set_arith(args.arith)
+    arith = E.arith_name()
+    fwd_flops, first_flops = conv_flops_per_image(build_model(args), args.size)
 
     primary_trainer = args.path == "trainer"
     steps_t = args.steps if primary_trainer else args.module_steps
     warm_t = args.warmup if primary_trainer else 2
-    max_iter = steps_t + warm_t + 1 + ISO_STEPS
-    it = 0
-    for _ in range(warm_t):
-        tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
-        it += 1
-    kt = None
-    if rank == 0 and not args.no_kernel_timing:
-        kt = E.KernelTimer()
-        for e in tr.engines.values():
-            e.ktimer = kt
-    torch.cuda.synchronize()
-    if world > 1 or force_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(steps_t):
-        _, main_loss, aux_loss = tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
-        it += 1
-    torch.cuda.synchronize()
-    if world > 1 or force_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.time() - t0
-    if world > 1 or force_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss_val = float(main_loss.item())
-    sec_trainer = dt / steps_t
-
-    # Serialized leg (every rank runs it: the steps contain the SyncBN / gradient collectives): ISO_STEPS more steps
-    # with all kernels on one stream, HIP-event timed on rank 0 -> per-kernel rates that are not inflated by the
-    # side-stream concurrency of the timed region.
-    kt_iso = None
-    if not args.no_kernel_timing:
-        kt_iso = E.KernelTimer() if rank == 0 else None
-        saved = [(e, e.side_wgrad, e.hipri_main) for e in tr.engines.values()]
-        for e, _, _ in saved:
-            e.side_wgrad, e.hipri_main, e.ktimer = False, False, kt_iso
-        for _ in range(ISO_STEPS):
-            tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
-        torch.cuda.synchronize()
-        for e, sw, hp in saved:
-            e.side_wgrad, e.hipri_main, e.ktimer = sw, hp, None
-    exec_flops = kt_iso.mfma_flops() / ISO_STEPS if kt_iso is not None else None
-    kfam = kt_iso.summary() if kt_iso is not None else None
-    kfam_in = kt.summary() if kt is not None else None
-    roof = None
-    if kt is not None:
-        roof = kt_iso.roofline(PEAK_F32_MFMA_TFLOPS)
-        ins = kt.roofline(PEAK_F32_MFMA_TFLOPS, family=roof["kernel"])
-        roof["in_step"] = {k: ins[k] for k in ("achieved", "frac", "avg_launch_us", "launches")}
+    leg = trainer_leg(args, dev, world, rank, B, steps_t, warm_t, arith, not args.no_kernel_timing, dist_on)
+    sec_trainer, loss_trainer = leg["sec"], leg["loss"]
 
     # The other path: the reference's unchanged loop body on the nn.Module API (torch.optim.SGD, autograd, DDP).
-    # The Trainer's engine (activation arena, flat buffers) is released first.
-    n_sync = None
-    for e in tr.engines.values():
-        n_sync = getattr(e, "syncbn_collectives_per_step", None)
-    del tr, model, kt, kt_iso
-    torch.cuda.empty_cache()
-    loss_trainer = loss_val
+    # The second leg is a single-GPU comparison; in a multi-rank launch only the path that was asked for runs (a failure
+    # in an extra leg on one rank would hang the others in a collective).
     sec_module = loss_module = None
-    # the second leg is a single-GPU comparison; in a multi-rank launch only the path that was asked for runs (a failure in
-    # an extra leg on one rank would hang the others in a collective)
     if (args.module_steps > 0 and world == 1) or not primary_trainer:
         sec_module, loss_module = module_path_step_time(args, dev, world, rank, B,
                                                         args.module_steps if primary_trainer else args.steps,
                                                         2 if primary_trainer else args.warmup)
     if primary_trainer:
-        dt = sec_trainer * args.steps
+        dt, loss_val = sec_trainer * args.steps, loss_trainer
     else:
         dt, loss_val = sec_module * args.steps, loss_module
-    experiment = None
-    if world == 1 and not args.no_experiments:
+
+    # The exact-fp32 configuration (every product on v_mfma_f32_32x32x2_f32: the arithmetic of rounds 1-3), timed by the
+    # same protocol with the same number of steps in the same process, so that both figures are driver-timed.
+    exact = None
+    if world == 1 and not args.no_exact and arith != "f32":
         try:
-            experiment = {
-                "what": "EXPERIMENT (review item 7), not the reported configuration and not part of `value`: "
-                        "SEMSEG_SPLIT_BF16=6 - fp32 operands cut into three bf16 pieces in flight, six cross products on "
-                        "the bf16 matrix-core instruction, fp32 accumulation; cls.0 only, and every eligible conv (1x1 "
-                        "forward / data gradient, Winograd GEMMs, 128x128 weight gradients); every parity criterion "
-                        "unchanged and green with it (DESIGN.md section 8.4, profiles/r03_insitu_split_bf16x6.txt)",
-                "dtype": "f32 via 3xbf16 split (6 cross products, fp32 accumulate)",
-                "cls0_only": split_bf16_experiment(args, dev, B, "cls.0"),
-                "all_eligible_convs": split_bf16_experiment(args, dev, B, "all")}
-        except Exception as e:                       # a side measurement never takes the bench line down
-            experiment = {"error": repr(e)}
+            ex = trainer_leg(args, dev, world, rank, B, args.steps, args.warmup, "f32", not args.no_kernel_timing, dist_on)
+            exact = {"what": "the same Trainer step with SEMSEG_ARITH_F32 on every conv GEMM (SEMSEG_ARITH=f32): exact fp32 "
+                             "products on the fp32-input matrix-core instruction, the headline configuration of rounds 1-3",
+                     "dtype": "f32", "ms_per_step": round(ex["sec"] * 1e3, 3),
+                     "images_per_sec": round(args.global_batch / ex["sec"], 3), "steps": args.steps, "warmup": args.warmup,
+                     "final_main_loss": round(ex["loss"], 5), "roofline": ex.get("roofline")}
+            if "exec_flops" in ex:
+                exact["executed_mfma_tflop_per_step"] = round(ex["exec_flops"] / 1e12, 3)
+                exact["whole_step_frac_of_f32_mfma_peak"] = round(ex["exec_flops"] / ex["sec"] / 1e12 /
+                                                                  PEAK_F32_MFMA_TFLOPS, 4)
+                exact["kernel_families"] = ex["kernel_families"]
+        except Exception as e:                       # the comparison leg never takes the bench line down
+            exact = {"error": repr(e)}
 
     if rank == 0:
         ips = args.global_batch * args.steps / dt
         step_flops = (3.0 * fwd_flops - first_flops) * args.global_batch
+        dtype = ("f32 (3xbf16-split products, fp32 accumulate)" if arith == "bf16x3" else "f32")
         out = {
             "metric": "images/sec (train step) %s-%d %dx%d bs=%d" % ("PSPNet" if args.arch == "psp" else "PSANet",
                                                                  args.layers, args.size, args.size,
                                                                  args.global_batch),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "PS%sNet%d ADE20K-shape %dx%d, %d classes, global batch %d (per-GPU %d), "
                                    "train step fwd+loss+bwd+SGD, SyncBN, random-init weights"
                                    % ("P" if args.arch == "psp" else "A", args.layers, args.size, args.size,
@@ -415,19 +416,31 @@ def main():
                        "parallelism": "dp%d" % world,
                        "path": ("semseg_amd.Trainer (fused loop body of tool/train.py:269-276)" if primary_trainer else
                                 "nn.Module drop-in + torch.optim.SGD (tool/train.py:269-276 unchanged)"),
+                       "arith": ("SEMSEG_ARITH_BF16X3 per launch on %d of the network's conv layers (forward, data gradient, "
+                                 "weight gradient; include/semseg_hip.h): fp32 operands in HBM, each cut in flight into "
+                                 "three bf16 pieces carrying all 24 mantissa bits, six cross products on "
+                                 "v_mfma_f32_32x32x16_bf16, fp32 accumulation; everything that is not a conv GEMM is "
+                                 "fp32" % leg.get("convs_bf16x3", 0)) if arith == "bf16x3" else
+                                "SEMSEG_ARITH_F32: exact fp32 products on v_mfma_f32_32x32x2_f32",
+                       "two_stream_backward": leg.get("two_stream_backward"),
                        "tile_table": _tile_summary()},
             "final_main_loss": round(loss_val, 5),
             # direct-convolution FLOPs of the step (SURVEY.md section 8d / BASELINE.md section 4: 3 x forward - first conv's
             # data gradient) — the work the metric is defined on; the stride-1 3x3 convs with >= 128 channels EXECUTE
-            # 1 / 2.25 of their share (Winograd F(2x2,3x3), fp32), so this rate can exceed what the matrix cores ran
+            # 1 / 2.25 of their share (Winograd F(2x2,3x3)), so this rate can exceed what the matrix cores ran
             "algorithmic_tflop_per_step": round(step_flops / 1e12, 3),
             "algorithmic_tflops_over_f32_mfma_peak": round(step_flops / (dt / args.steps) / 1e12 / world /
                                                            PEAK_F32_MFMA_TFLOPS, 4),
         }
-        if exec_flops is not None:
-            out["executed_mfma_tflop_per_step"] = round(exec_flops * world / 1e12, 3)
-            out["whole_step_frac_of_f32_mfma_peak"] = round(exec_flops / (dt / args.steps) / 1e12 /
-                                                            PEAK_F32_MFMA_TFLOPS, 4)
+        if "exec_flops" in leg and primary_trainer:
+            # executed matrix-core FLOPs (fp32-equivalent: one multiply-add = 2, however many bf16 products form it) are
+            # measured on the Trainer leg, so they are only reported against the Trainer leg's step time
+            rate = leg["exec_flops"] / (dt / args.steps) / 1e12
+            out["executed_mfma_tflop_per_step"] = round(leg["exec_flops"] * world / 1e12, 3)
+            out["whole_step_executed_tflops"] = round(rate, 2)
+            out["whole_step_frac_of_f32_mfma_peak"] = round(rate / PEAK_F32_MFMA_TFLOPS, 4)
+            if arith == "bf16x3":
+                out["whole_step_frac_of_bf16x3_peak"] = round(rate / PEAK_BF16X3_TFLOPS, 4)
         other = sec_module if primary_trainer else sec_trainer
         if other is not None:
             out["module_path" if primary_trainer else "trainer_path"] = {
@@ -436,39 +449,48 @@ def main():
                          else "semseg_amd.Trainer fused step"),
                 "ms_per_step": round(other * 1e3, 3), "images_per_sec": round(args.global_batch / other, 3),
                 "steps": args.module_steps, "final_main_loss": round(loss_module if primary_trainer else loss_trainer, 5)}
-        if experiment is not None:
-            out["experiment_split_bf16x6"] = experiment
-        if n_sync is not None:
-            out["syncbn_collectives_per_step"] = n_sync
+        if exact is not None:
+            out["exact_fp32"] = exact
+        if leg.get("n_sync") is not None:
+            out["syncbn_collectives_per_step"] = leg["n_sync"]
+        roof = leg.get("roofline")
         if roof is not None:
-            # roofline of the dominant kernel family = the serialized leg above (the kernel has the chip to itself);
-            # what the same family shows inside the timed region, where it shares the chip, is reported next to it
+            # roofline of the dominant kernel family = the serialized leg (the kernel has the chip to itself);
+            # what the same family shows inside the timed region, where it may share the chip, is reported next to it
+            roof["peak_note"] = ("bf16x3 kernels: dense bf16 matrix-core peak %.0f TFLOP/s / 6 products = %.1f TFLOP/s "
+                                 "fp32-equivalent; fp32-instruction kernels: %.1f" % (PEAK_BF16_MFMA_TFLOPS,
+                                                                                     PEAK_BF16X3_TFLOPS,
+                                                                                     PEAK_F32_MFMA_TFLOPS))
             roof["measured"] = ("HIP events on the launch stream over %d steps run right after the timed region with "
-                                "every kernel on ONE stream; in the timed region the weight gradients run on a side "
-                                "stream concurrently with the data-gradient / BatchNorm chain, so a launch's duration "
-                                "there includes sharing the chip (in_step)" % ISO_STEPS)
-            # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3
-            # cannot run inside this process; the file records the exact commands and corrections)
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
-                key = roof["kernel"].split("+")[0].split("(")[0].replace(" ", "")
-                for k, v in pmc.items():
-                    if k.replace(" ", "") == key:
-                        roof["traffic"] = v["hbm_bytes_per_launch"]
-                        roof["traffic_unit"] = ("bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/" + PMC_FILE
-                                                + (")" if world == 1 else "; collected at n_gpus=1, per-GPU batch 16)"))
-                        roof["mfma_busy_frac_pmc"] = v.get("mfma_busy_frac")
-            except Exception:
-                pass
+                                "every kernel on ONE stream (in_step: the same family inside the timed region)" % ISO_STEPS)
+            _attach_pmc(roof, world)
             out["roofline"] = roof
-            out["kernel_families"] = kfam
-            out["kernel_families_in_step"] = kfam_in
+            out["kernel_families"] = leg["kernel_families"]
+            out["kernel_families_in_step"] = leg["kernel_families_in_step"]
+            if exact is not None and isinstance(exact.get("roofline"), dict):
+                _attach_pmc(exact["roofline"], world)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.layers, args.classes, args.size, arch=args.arch)
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1 or force_dist:
+    if dist_on:
         dist.destroy_process_group()
+
+
+def _attach_pmc(roof, world):
+    """HBM traffic / matrix-pipe busy fraction of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot
+    run inside this process; the file records the exact commands and corrections)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
+        key = roof["kernel"].split("+")[0].split("(")[0].replace(" ", "")
+        for k, v in pmc.items():
+            if k.replace(" ", "") == key:
+                roof["traffic"] = v["hbm_bytes_per_launch"]
+                roof["traffic_unit"] = ("bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/" + PMC_FILE
+                                        + (")" if world == 1 else "; collected at n_gpus=1, per-GPU batch 16)"))
+                roof["mfma_busy_frac_pmc"] = v.get("mfma_busy_frac")
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":

@@ -31,6 +31,22 @@ int semseg_psamask_backward(int psa_type, const float* grad_output, float* grad_
                             int feature_H_, int feature_W_, int mask_H_, int mask_W_,
                             int half_mask_H_, int half_mask_W_, hipStream_t stream);
 
+/* ---- Arithmetic of the matrix-core products: a PER-LAUNCH argument (`arith`) of every entry point below that runs
+ * a GEMM on the matrix cores.  Operands, accumulators and results are fp32 in both cases.
+ *   SEMSEG_ARITH_F32     exact fp32 products: v_mfma_f32_32x32x2_f32 (bit-wise an fmaf chain).
+ *   SEMSEG_ARITH_BF16X3  every fp32 operand is cut IN FLIGHT (between the global load and the LDS store; HBM keeps
+ *                        fp32) into three bf16 pieces h + m + l, round-to-nearest at every level, remainders exact in
+ *                        fp32, so the pieces carry all 24 mantissa bits; the product is rebuilt from the six leading
+ *                        cross products ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm on v_mfma_f32_32x32x16_bf16
+ *                        (each exact in fp32; the three dropped ones are below 2^-24 of the result) with fp32
+ *                        accumulation.  Measured error at or below the fp32 instruction's in every parity test
+ *                        (DESIGN.md section 8.4).  Kernel instances without a split form (generic tap walk, 64 x 64
+ *                        weight-gradient tiles) compute exact fp32 products under either value: `arith` never makes
+ *                        a launch LESS precise than SEMSEG_ARITH_BF16X3.
+ * Any other value: SEMSEG_EINVAL (-1).  No process-wide state is involved: concurrent launches on different streams /
+ * host threads may use different values. */
+enum { SEMSEG_ARITH_F32 = 0, SEMSEG_ARITH_BF16X3 = 3 };
+
 /* ---- nn.Conv2d (reference call sites: model/resnet.py:63-69,108-112,134; model/pspnet.py:15,65,
  * 69,73,77; dilation surgery model/pspnet.py:49-58; model/psanet.py:25-48).
  * pack: OIHW -> K-contiguous panels consumed by fwd ([Co_pad][Ci*R*S]) and dgrad
@@ -57,13 +73,13 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
                     int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
                     int dil, const float* bias, const float* scale, int relu, const float* add,
-                    int ldadd, double* stats, int stats_nslot, int tile_n, float* scratch,
+                    int ldadd, double* stats, int stats_nslot, int tile_n, int arith, float* scratch,
                     size_t scratch_floats, hipStream_t stream);
 /* dx[N*H*W][Ci] = conv_transpose(dy) (+add).  dy must be readable (zero padded) up to
  * roundup32(Co) channels; w_dgrad must have roundup(Ci, tile_n) rows. */
 int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
-                      int pad, int dil, const float* add, int ldadd, int tile_n, float* scratch,
+                      int pad, int dil, const float* add, int ldadd, int tile_n, int arith, float* scratch,
                       size_t scratch_floats, hipStream_t stream);
 /* Data gradient + the BatchNorm-backward reduction (torch batch_norm backward for model/resnet.py:76-92) of the
  * layer(s) that PRODUCED this conv's input, in one kernel: dx = g = (dgrad (+ add)) * (act > 0), and
@@ -75,7 +91,7 @@ int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, 
                                const float* add, int ldadd, int tile_n, int bn_count, const float* act, int ldact,
                                const float* y0, int ldy0, const float* mean0, const float* invstd0, double* sums0,
                                const float* y1, int ldy1, const float* mean1, const float* invstd1, double* sums1,
-                               int nslot, float* scratch, size_t scratch_floats, hipStream_t stream);
+                               int nslot, int arith, float* scratch, size_t scratch_floats, hipStream_t stream);
 /* dw_oihw[Co][Ci][R][S] (=|+=) sum over pixels; scratch holds the split-K partial slabs
  * (>= semseg_conv_wgrad_scratch_floats(...) floats; more slabs => more K parallelism AND shorter fp32
  * accumulation chains: with a single slab the whole pixel reduction is one chain and its rounding noise
@@ -84,7 +100,7 @@ int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, 
 int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
                       float* scratch, size_t scratch_floats, int N, int H, int W, int Ci, int Ho,
                       int Wo, int Co, int R, int S, int stride, int pad, int dil, int accumulate,
-                      hipStream_t stream);
+                      int arith, hipStream_t stream);
 size_t semseg_conv_wgrad_scratch_floats(int Ci, int Co, int R, int S);
 
 /* Batched GEMMs on the same two matrix-core kernels (one launch, blockIdx.y = batch item; strides in floats) — the
@@ -92,21 +108,18 @@ size_t semseg_conv_wgrad_scratch_floats(int Ci, int Co, int R, int S);
  *   rows:   C[b][M][Nout] = A[b][M][K] * Bt[b][Nout_pad][K]^T   (K % 32 == 0; Bt rows >= Nout readable, zero)
  *   kmajor: out[b][Co][Ci] (=|+=) sum_k y[b][k][co] * x[b][k][ci]  (Ci % 64 == 0; scratch holds batch slab sets) */
 int semseg_gemm_rows_batched(const float* a, int lda, long long a_bs, const float* bt, long long bt_bs, float* c,
-                             int ldc, long long c_bs, int M, int K, int Nout, int batch, hipStream_t stream);
+                             int ldc, long long c_bs, int M, int K, int Nout, int batch, int arith,
+                             hipStream_t stream);
 int semseg_gemm_kmajor_batched(const float* x, int ldx, long long x_bs, const float* y, int ldy, long long y_bs,
                                float* out, long long out_bs, float* scratch, size_t scratch_floats, int K, int Ci,
-                               int Co, int accumulate, int batch, hipStream_t stream);
+                               int Co, int accumulate, int batch, int arith, hipStream_t stream);
 
-/* EXPERIMENT (engine flag SEMSEG_SPLIT_BF16, off by default and never part of the reported
- * configuration): semseg_gemm_rows_batched with each fp32 operand split in flight into nsplit bf16 pieces (2: a*b ~
- * ah*bh + ah*bl + al*bh, ~2^-16 per product; 3: six products, ~2^-23) and multiplied on v_mfma_f32_32x32x16_bf16 with
- * fp32 accumulation.  Same operands and strides; bk = 16 | 32 (32 only with nsplit 2), K % bk == 0, lda % 4 == 0,
- * Bt rows readable up to roundup(Nout, 128). */
-/* EXPERIMENT switch, process-wide, not thread-safe: pieces = 3 makes the 1x1 / GEMM instances of semseg_conv_fwd,
- * semseg_conv_dgrad (+ fused BatchNorm-backward reduction) and semseg_gemm_rows[_batched] form their products from three-way
- * split bf16 pieces (six bf16 matrix-core instructions per 16 K, fp32 accumulation, same epilogues); 0 restores the fp32
- * instructions.  Returns the previous value. */
-int semseg_experiment_conv_split(int pieces);
+/* semseg_gemm_rows_batched with SEMSEG_ARITH_BF16X3 products on a kernel of its own (256 x 128 tile, 8 waves,
+ * chunk-swizzled unpadded piece planes; csrc/gemm_bf16split.hip) — what the engine runs for the 16 batched GEMMs of a
+ * Winograd forward / data gradient.  Same operands and strides; nsplit = 3 (three pieces, six products: the arithmetic
+ * above), bk = 16, K % 16 == 0, lda % 4 == 0, Bt rows readable up to roundup(Nout, 128).
+ * nsplit = 2 (two pieces, three products, ~2^-16 per product; bk 16 | 32) is kept as a MEASUREMENT only: it fails the
+ * per-op parity criteria and nothing in the engine selects it. */
 int semseg_gemm_rows_batched_bf16split(const float* a, int lda, long long a_bs, const float* bt, long long bt_bs,
                                        float* c, int ldc, long long c_bs, int M, int K, int Nout, int batch, int nsplit,
                                        int bk, hipStream_t stream);

@@ -330,7 +330,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
 // carry an out-of-range offset, which the buffer unit returns as 0) plus one scalar offset per K-step —
 // no per-K-step address VALU between the MFMAs at all.
 //
-// SP (EXPERIMENT; 0 in every reported configuration): SP = 3 cuts each fp32 operand into three
+// SP = 3 (SEMSEG_ARITH_BF16X3, include/semseg_hip.h) cuts each fp32 operand into three
 // bf16 pieces between the global load and the LDS store and forms the product from six v_mfma_f32_32x32x16_bf16 per
 // 16 K instead of eight v_mfma_f32_32x32x2_f32 — same gather, same accumulators, same epilogues.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -862,7 +862,7 @@ struct WgradArgs {
 // MODE 0: generic gather (any stride / padding).  MODE 1: 1x1, stride 1, pad 0 — the gathered row IS row m,
 // no decode, always valid.  MODE 2: stride 1 with Ho x Wo == Hin x Win ("same" 3x3, any dilation) — the
 // gathered row is m + tap offset (linear); the pixel is decoded only for the border test.
-// SP (EXPERIMENT; 0 in every reported configuration): SP = 3, 128 x 128 only — each thread
+// SP = 3 (SEMSEG_ARITH_BF16X3, include/semseg_hip.h), 128 x 128 only — each thread
 // stages FOUR CONSECUTIVE pixels of its four channels, cuts them into three bf16 pieces and stores them pixel-contiguous
 // ([channel][32 pixels] planes, the layout the bf16 matrix-core instruction wants for a K-major operand), and the
 // product is formed from six v_mfma_f32_32x32x16_bf16 per 16 pixels.
@@ -1441,17 +1441,13 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 // splitting K, so no partial slabs and no separate epilogue pass
 static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064 || t == 1128; }
 
-// EXPERIMENT switch, process-wide and not thread-safe: 3 = the 1x1 / GEMM and 3x3 instances of the
-// forward / data-gradient kernel form their products from three-way split bf16 pieces.  0 (default) everywhere that is reported.
-static int g_conv_split = 0;
-int semseg_experiment_conv_split(int pieces) {
-  const int old = g_conv_split;
-  if (pieces == 0 || pieces == 3) g_conv_split = pieces;
-  return old;
-}
+static inline bool arith_ok(int a) { return a == SEMSEG_ARITH_F32 || a == SEMSEG_ARITH_BF16X3; }
 
-static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, float* scratch,
+// arith (include/semseg_hip.h): SEMSEG_ARITH_BF16X3 selects the SP = 3 instances of the 1x1 / 3x3 buffer-load kernels
+// (products from three-way split bf16 pieces); the generic tap walk (RS_T = 0) has no split form and stays exact fp32.
+static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, int arith, float* scratch,
                        size_t scratch_floats, hipStream_t stream) {
+  const bool sp3 = arith == SEMSEG_ARITH_BF16X3;
   const int BMr = tile_code >= 1000 ? 64 : 128;
   const int BN = tile_code % 1000;
   const int tiles_m = (a.M + BMr - 1) / BMr;
@@ -1530,11 +1526,11 @@ static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, float*
   } while (0)
 #define LAUNCH_RS(BM_, BN_, TR_)                                   \
   do {                                                             \
-    if (bl && RSv == 9 && g_conv_split == 3) {                     \
+    if (bl && RSv == 9 && sp3) {                     \
       if (tl) conv_igemm_kernel<BM_, BN_, TR_, 9, true, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);   \
       else conv_igemm_kernel<BM_, BN_, TR_, 9, false, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);     \
     } else if (bl && RSv == 9) LAUNCH_CONV(BM_, BN_, TR_, 9);      \
-    else if (bl && g_conv_split == 3) {                            \
+    else if (bl && sp3) {                            \
       if (tl) conv_igemm_kernel<BM_, BN_, TR_, 1, true, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);   \
       else conv_igemm_kernel<BM_, BN_, TR_, 1, false, 3><<<dim3(grid, p.batch), BM_ * 2, 0, stream>>>(p);     \
     } else if (bl) LAUNCH_CONV(BM_, BN_, TR_, 1);                  \
@@ -1585,9 +1581,9 @@ static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, float*
 int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
                     int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
                     int dil, const float* bias, const float* scale, int relu, const float* add,
-                    int ldadd, double* stats, int stats_nslot, int tile_n, float* scratch,
+                    int ldadd, double* stats, int stats_nslot, int tile_n, int arith, float* scratch,
                     size_t scratch_floats, hipStream_t stream) {
-  if (!x || !w_fwd || !y || Ci % 32 != 0 || (ldx & 3) || !tile_code_ok(tile_n))
+  if (!x || !w_fwd || !y || Ci % 32 != 0 || (ldx & 3) || !tile_code_ok(tile_n) || !arith_ok(arith))
     return SEMSEG_EINVAL;
   ConvArgs a;
   a.x = x; a.w = w_fwd; a.y = y; a.bias = bias; a.scale = scale; a.relu = relu; a.add = add; a.stats = stats;
@@ -1596,14 +1592,14 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
   a.Kc = Ci; a.Nout = Co; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * Ho * Wo; a.tiles_n = 0; a.stats_nslot = stats_nslot > 0 ? stats_nslot : 1;
   a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0; a.bnr_n = 0; a.bnr_mask = nullptr;
-  return conv_launch(false, a, tile_n, scratch, scratch_floats, stream);
+  return conv_launch(false, a, tile_n, arith, scratch, scratch_floats, stream);
 }
 
 static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
-                      int pad, int dil, const float* add, int ldadd, int tile_n, const ConvArgs* bnr, float* scratch,
-                      size_t scratch_floats, hipStream_t stream) {
-  if (!dy || !w_dgrad || !dx || (lddy & 3) || !tile_code_ok(tile_n)) return SEMSEG_EINVAL;
+                      int pad, int dil, const float* add, int ldadd, int tile_n, int arith, const ConvArgs* bnr,
+                      float* scratch, size_t scratch_floats, hipStream_t stream) {
+  if (!dy || !w_dgrad || !dx || (lddy & 3) || !tile_code_ok(tile_n) || !arith_ok(arith)) return SEMSEG_EINVAL;
   const int Kc = (Co + 31) / 32 * 32;
   if (lddy < Kc) return SEMSEG_EINVAL;
   ConvArgs a;
@@ -1620,15 +1616,15 @@ static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx
       a.bnr_invstd[b] = bnr->bnr_invstd[b]; a.bnr_sums[b] = bnr->bnr_sums[b];
     }
   }
-  return conv_launch(true, a, tile_n, scratch, scratch_floats, stream);
+  return conv_launch(true, a, tile_n, arith, scratch, scratch_floats, stream);
 }
 
 int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
-                      int pad, int dil, const float* add, int ldadd, int tile_n, float* scratch,
+                      int pad, int dil, const float* add, int ldadd, int tile_n, int arith, float* scratch,
                       size_t scratch_floats, hipStream_t stream) {
   return dgrad_impl(dy, lddy, w_dgrad, dx, lddx, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, add, ldadd, tile_n,
-                    nullptr, scratch, scratch_floats, stream);
+                    arith, nullptr, scratch, scratch_floats, stream);
 }
 
 // Data gradient + the BatchNorm-backward reduction of the layer(s) that PRODUCED this conv's input, in one kernel:
@@ -1640,7 +1636,7 @@ int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, 
                                const float* add, int ldadd, int tile_n, int bn_count, const float* act, int ldact,
                                const float* y0, int ldy0, const float* mean0, const float* invstd0, double* sums0,
                                const float* y1, int ldy1, const float* mean1, const float* invstd1, double* sums1,
-                               int nslot, float* scratch, size_t scratch_floats, hipStream_t stream) {
+                               int nslot, int arith, float* scratch, size_t scratch_floats, hipStream_t stream) {
   if (bn_count < 1 || bn_count > 2 || !y0 || !mean0 || !invstd0 || !sums0 || nslot < 1) return SEMSEG_EINVAL;
   if (bn_count == 2 && (!y1 || !mean1 || !invstd1 || !sums1)) return SEMSEG_EINVAL;
   // the fused path lives in the 16-byte store phase of the epilogue: everything 4-float aligned, channels % 4 == 0
@@ -1651,15 +1647,15 @@ int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, 
   b.bnr_n = bn_count; b.bnr_mask = act; b.bnr_ldm = ldact; b.stats_nslot = nslot;
   b.bnr_y[0] = y0; b.bnr_ldy[0] = ldy0; b.bnr_mean[0] = mean0; b.bnr_invstd[0] = invstd0; b.bnr_sums[0] = sums0;
   b.bnr_y[1] = y1; b.bnr_ldy[1] = ldy1; b.bnr_mean[1] = mean1; b.bnr_invstd[1] = invstd1; b.bnr_sums[1] = sums1;
-  return dgrad_impl(dy, lddy, w_dgrad, dx, lddx, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, add, ldadd, tile_n, &b,
-                    scratch, scratch_floats, stream);
+  return dgrad_impl(dy, lddy, w_dgrad, dx, lddx, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, add, ldadd, tile_n,
+                    arith, &b, scratch, scratch_floats, stream);
 }
 
 static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
                         float* scratch, size_t scratch_floats, int N, int H, int W, int Ci, int Ho,
                         int Wo, int Co, int R, int S, int stride, int pad, int dil, int accumulate,
-                        int batch, long long x_bs, long long dy_bs, long long out_bs, hipStream_t stream) {
-  if (!x || !dy || !dw_oihw || !scratch || (ldx & 3) || (lddy & 3) || Ci % 64 != 0 || batch < 1)
+                        int batch, long long x_bs, long long dy_bs, long long out_bs, int arith, hipStream_t stream) {
+  if (!x || !dy || !dw_oihw || !scratch || (ldx & 3) || (lddy & 3) || Ci % 64 != 0 || batch < 1 || !arith_ok(arith))
     return SEMSEG_EINVAL;
   const int RS = R * S;
   const int M = N * Ho * Wo;
@@ -1718,7 +1714,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
     if (tiles > thr) dma_env = vb;
   }
   const bool dma_ok = (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
-  const bool sp = big && g_conv_split == 3;      // EXPERIMENT: register-staged 128 x 128 kernel, split-bf16 products
+  const bool sp = big && arith == SEMSEG_ARITH_BF16X3;   // register-staged 128 x 128 kernel, split-bf16 products
   const int dma = (big && !sp && dma_ok && dma_env >= 0 && dma_env <= 7) ? dma_env : 0;
   static const int occ_of[8] = {3, 2, 3, 2, 5, 5, 2, 2};
   // Fill whole residency rounds (256 CUs x resident workgroups per CU): among the K splits that give at most two
@@ -1782,9 +1778,9 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
 int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_oihw,
                       float* scratch, size_t scratch_floats, int N, int H, int W, int Ci, int Ho,
                       int Wo, int Co, int R, int S, int stride, int pad, int dil, int accumulate,
-                      hipStream_t stream) {
+                      int arith, hipStream_t stream) {
   return wgrad_launch(x, ldx, dy, lddy, dw_oihw, scratch, scratch_floats, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad,
-                      dil, accumulate, 1, 0, 0, 0, stream);
+                      dil, accumulate, 1, 0, 0, 0, arith, stream);
 }
 
 // Batched GEMMs on the two matrix-core kernels — the PSA point-affinity contraction (torch.bmm at
@@ -1792,8 +1788,9 @@ int semseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
 //   rows:   C[b][M][Nout] (+= add) = A[b][M][K] * Bt[b][Nout_pad][K]^T      (K % 32 == 0, Bt rows zero padded)
 //   kmajor: out[b][Co][Ci] (=|+=) sum_k y[b][k][co] * x[b][k][ci]           (Ci % 64 == 0)
 int semseg_gemm_rows_batched(const float* a, int lda, long long a_bs, const float* bt, long long bt_bs, float* c,
-                             int ldc, long long c_bs, int M, int K, int Nout, int batch, hipStream_t stream) {
-  if (!a || !bt || !c || K % 32 != 0 || (lda & 3) || batch < 1 || batch > 65535) return SEMSEG_EINVAL;
+                             int ldc, long long c_bs, int M, int K, int Nout, int batch, int arith,
+                             hipStream_t stream) {
+  if (!a || !bt || !c || K % 32 != 0 || (lda & 3) || batch < 1 || batch > 65535 || !arith_ok(arith)) return SEMSEG_EINVAL;
   ConvArgs g;
   g.x = a; g.w = bt; g.y = c; g.bias = nullptr; g.scale = nullptr; g.relu = 0; g.add = nullptr; g.stats = nullptr;
   g.ldx = lda; g.ldy = ldc; g.ldadd = 0;
@@ -1801,12 +1798,12 @@ int semseg_gemm_rows_batched(const float* a, int lda, long long a_bs, const floa
   g.Kc = K; g.Nout = Nout; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.dil = 1;
   g.M = M; g.tiles_n = 0; g.stats_nslot = 1;
   g.batch = batch; g.x_bs = a_bs; g.w_bs = bt_bs; g.y_bs = c_bs; g.add_bs = 0; g.bnr_n = 0; g.bnr_mask = nullptr;
-  return conv_launch(false, g, Nout >= 128 ? 128 : 64, nullptr, 0, stream);
+  return conv_launch(false, g, Nout >= 128 ? 128 : 64, arith, nullptr, 0, stream);
 }
 
 int semseg_gemm_kmajor_batched(const float* x, int ldx, long long x_bs, const float* y, int ldy, long long y_bs,
                                float* out, long long out_bs, float* scratch, size_t scratch_floats, int K, int Ci,
-                               int Co, int accumulate, int batch, hipStream_t stream) {
+                               int Co, int accumulate, int batch, int arith, hipStream_t stream) {
   if (batch < 1 || batch > 65535) return SEMSEG_EINVAL;
   // every batch item needs at least one partial slab of the scratch arena: a batch that does not fit runs in chunks
   const size_t slab = semseg_conv_wgrad_scratch_floats(Ci, Co, 1, 1);
@@ -1816,7 +1813,7 @@ int semseg_gemm_kmajor_batched(const float* x, int ldx, long long x_bs, const fl
     const int nb = batch - b0 < (int)fit ? batch - b0 : (int)fit;
     const int rc = wgrad_launch(x + (long long)b0 * x_bs, ldx, y + (long long)b0 * y_bs, ldy, out + (long long)b0 * out_bs,
                                 scratch, scratch_floats, 1, K, 1, Ci, K, 1, Co, 1, 1, 1, 0, 1, accumulate, nb, x_bs, y_bs,
-                                out_bs, stream);
+                                out_bs, arith, stream);
     if (rc != SEMSEG_OK) return rc;
   }
   return SEMSEG_OK;

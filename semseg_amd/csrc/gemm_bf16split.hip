@@ -1,10 +1,11 @@
-// EXPERIMENT, off by default (engine flag SEMSEG_SPLIT_BF16 = 3 | 6, never the reported configuration):
+// SEMSEG_ARITH_BF16X3 (include/semseg_hip.h) on a kernel of its own: what the engine runs for
 // the batched row GEMM of the Winograd path,  C[b][M][Nout] = A[b][M][K] * Bt[b][Nout_pad][K]^T  (same operands,
 // same layouts and strides as semseg_gemm_rows_batched), with each fp32 operand split on the fly into bf16 pieces
 // and the product rebuilt from bf16 matrix-core instructions (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate)
 // with fp32 accumulation:
-//   nsplit 2 ("x3"):  x = h + l,      a*b ~ ah*bh + ah*bl + al*bh                       (3 MFMAs, ~2^-16 per product)
-//   nsplit 3 ("x6"):  x = h + m + l,  a*b ~ ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm  (6 MFMAs, ~2^-23)
+//   nsplit 3 ("x6"):  x = h + m + l,  a*b ~ ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm  (6 MFMAs, ~2^-23) — the arithmetic
+//   nsplit 2 ("x3"):  x = h + l,      a*b ~ ah*bh + ah*bl + al*bh     (3 MFMAs, ~2^-16 per product) — a MEASUREMENT only, it
+//                     fails the per-op parity criteria and nothing in the engine selects it
 // The operands stay fp32 in HBM; the split happens in registers between the global load and the LDS store, so the
 // kernel is a drop-in for the fp32 one.  What it costs in accuracy is measured by scripts/split_bf16_probe.py and the
 // in-situ test; DESIGN.md section 8.4 has the numbers.

@@ -140,4 +140,8 @@ class DeviceLoader(object):
             yield self.collate(raw)
 
     def __getattr__(self, name):
+        # only reached for attributes this object does not have: forward plain attributes to the DataLoader, but never
+        # dunder probes (copy / pickle protocols) and never before `loader` exists (that lookup would recurse)
+        if name.startswith("__") or "loader" not in self.__dict__:
+            raise AttributeError(name)
         return getattr(self.loader, name)

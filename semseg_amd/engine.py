@@ -61,6 +61,11 @@ class KernelTimer:
         """FLOPs executed on the matrix cores over everything recorded (Winograd GEMMs count what they execute)."""
         return sum(fl for _, fl, _, _ in self.rec if fl > 0)
 
+    def dominant_family(self):
+        """The matrix-core family with the largest total time."""
+        fam = {k: v for k, v in self._collect().items() if v[1] > 0}
+        return max(fam.items(), key=lambda kv: kv[1][2])[0]
+
     def roofline(self, peak_tflops, family=None):
         fam = self._collect()
         fam = {k: v for k, v in fam.items() if v[1] > 0}      # matrix-core families only
@@ -112,24 +117,83 @@ class Act:
 
 WINO_HBM = "wino_input / wino_output / wino_dy_wgrad / wino_filter_grad kernels (Winograd transforms, HBM-bound)"
 WINOGRAD = os.environ.get("SEMSEG_WINOGRAD", "1") != "0"   # 0: every 3x3 conv on the direct implicit-GEMM kernels (A/B)
-# EXPERIMENT, never the reported configuration: 3 | 6 routes the forward and data-gradient row
-# GEMMs of the named Winograd convs through the split-bf16 kernel (csrc/gemm_bf16split.hip; 3 = two pieces / three
-# MFMAs, 6 = three pieces / six MFMAs).  0 = fp32 matrix-core instructions everywhere.
-SPLIT_BF16 = int(os.environ.get("SEMSEG_SPLIT_BF16", "0"))
-SPLIT_LAYERS = os.environ.get("SEMSEG_SPLIT_LAYERS", "cls.0").split(",")
-# with 6: which kernel runs the Winograd row GEMMs — "standalone" (gemm_bf16split.hip) or "igemm" (the SP instances of
-# conv_igemm_kernel, which the 1x1 convs of the named layers use in any case)
-SPLIT_WINO_KERNEL = os.environ.get("SEMSEG_SPLIT_WINO_KERNEL", "standalone")
-# with 6: weight gradients of the named layers with >= 128 x 128 channels on the SP instance of conv_wgrad_kernel too
-SPLIT_WGRAD = os.environ.get("SEMSEG_SPLIT_WGRAD", "1") != "0"
+# Arithmetic of the matrix-core products of every conv GEMM of an engine (include/semseg_hip.h):
+#   "bf16x3" (default)  SEMSEG_ARITH_BF16X3: each fp32 operand cut in flight into three bf16 pieces (all 24 mantissa bits),
+#                       six cross products on the bf16 matrix-core instruction, fp32 accumulation — fp32-grade by every
+#                       parity criterion of this repo (in situ: at or below the fp32 instruction's error)
+#   "f32"               SEMSEG_ARITH_F32: exact fp32 products everywhere (the configuration of rounds 1-3)
+# Read when an Engine is BUILT (SEMSEG_ARITH in the environment, or set_arith() before the first forward of a model /
+# Trainer); it is handed to the C ABI per launch, there is no process-wide switch in the library.
+_ARITH_NAMES = {"f32": ops.ARITH_F32, "bf16x3": ops.ARITH_BF16X3}
+ARITH = _ARITH_NAMES[os.environ.get("SEMSEG_ARITH", "bf16x3")]
+# which kernel runs the 16 batched row GEMMs of a Winograd forward / data gradient under bf16x3: "standalone" (256 x 128
+# tiles, csrc/gemm_bf16split.hip; 197 vs 182 TFLOP/s fp32-equivalent on cls.0) or "igemm" (the SP instances of
+# conv_igemm_kernel that the 1x1 convs run)
+WINO_BF16X3_KERNEL = os.environ.get("SEMSEG_WINO_GEMM", "standalone")
+
+
+def set_arith(name):
+    """"bf16x3" | "f32" for engines built from now on; returns the previous name."""
+    global ARITH
+    old = arith_name()
+    ARITH = _ARITH_NAMES[name]
+    return old
+
+
+def arith_name(a=None):
+    a = ARITH if a is None else a
+    return "f32" if a == ops.ARITH_F32 else "bf16x3"
+
+
+def _fam(arith):
+    """Suffix of a kernel-family label: the SP = 3 template instances run under bf16x3."""
+    return ",SP3" if arith == ops.ARITH_BF16X3 else ""
+
+
+class LabelWatch:
+    """Ring of pinned host slots receiving, behind every training step's loss head, the number of labels that were neither
+    ignore_index nor a class id (acc[2] of semseg_ce_head_fwd).  One per model.  Nothing is dropped: when the host runs
+    more than RING steps ahead of the device, the oldest copy is waited for before its slot is reused."""
+    RING = 8
+
+    def __init__(self):
+        self.host = torch.zeros(self.RING, dtype=F64).pin_memory()
+        self.events = [None] * self.RING
+        self.n = 0
+
+    def watch(self, acc):
+        i = self.n % self.RING
+        self.n += 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+            self._take(i, None)
+        self.host[i:i + 1].copy_(acc[2:3], non_blocking=True)
+        self.events[i] = torch.cuda.Event()
+        self.events[i].record()
+
+    def _take(self, i, nclasses):
+        self.events[i] = None
+        nbad = int(self.host[i].item())
+        if nbad:
+            raise IndexError("Target out of bounds: %d label(s) of an earlier step were neither ignore_index nor in "
+                             "[0, %s) (counted by the fused loss head)" % (nbad, "C" if nclasses is None else nclasses))
+
+    def poll(self, nclasses=None, wait=False):
+        for i, ev in enumerate(self.events):
+            if ev is None:
+                continue
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                continue
+            self._take(i, nclasses)
 
 
 class ConvL:
-    def __init__(self, mod, device, need_dgrad=True, training=True, name=""):
+    def __init__(self, mod, device, need_dgrad=True, training=True, name="", arith=ops.ARITH_F32):
         w = mod.weight
         self.mod = mod
-        self.split = 0
-        self.split_w = SPLIT_BF16 == 6 and SPLIT_WGRAD and (name in SPLIT_LAYERS or "all" in SPLIT_LAYERS)
+        self.arith = arith      # per-launch argument of this layer's forward / data-gradient / weight-gradient GEMMs
         self.Co, self.Ci, self.R, self.S = w.shape
         self.stride, self.pad, self.dil = mod.stride[0], mod.padding[0], mod.dilation[0]
         # Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convs (csrc/winograd.hip): 1 / 2.25 of the
@@ -144,13 +208,8 @@ class ConvL:
                 and self.Ci % 64 == 0 and self.Ci >= 128 and self.Co % 128 == 0 and mod.bias is None):
             self.wino = ops.WinoConv(self.Co, self.Ci, device, need_dgrad)
             self.pk = None
-            if SPLIT_BF16 and (name in SPLIT_LAYERS or "all" in SPLIT_LAYERS) and self.Ci % 128 == 0:
-                assert SPLIT_BF16 in (3, 6), "SEMSEG_SPLIT_BF16 must be 0, 3 or 6"
-                self.split = SPLIT_BF16
         else:
             self.pk = ops.PackedConv(self.Co, self.Ci, self.R, self.S, device, need_dgrad)
-            if SPLIT_BF16 == 6 and (name in SPLIT_LAYERS or "all" in SPLIT_LAYERS) and self.R * self.S in (1, 9):
-                self.split = 6      # forward / data gradient on the SP instances of conv_igemm_kernel
         self.wgrad = None
         self.bgrad = None
 
@@ -178,6 +237,7 @@ class BNL:
 # of the weight-gradient stream with the dependent chain (measured: 207 ms for the first engine of a process, 221-230
 # ms for an identical second one).  Engines of one process never run concurrently, so sharing is safe.
 _SHARED = {}
+MAX_SCRATCH_ARENAS = 4
 
 
 def _shared(device, name, make):
@@ -223,6 +283,7 @@ class Engine:
         self.tape = []
         self.convs = {}
         self.bns = {}
+        self.arith = ARITH
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         # SEMSEG_FORCE_DIST=1 drives the N>1 code path (collectives included) on a 1-rank group: the
         # only way to exercise the RCCL calls on a single-GPU test box
@@ -307,7 +368,7 @@ class Engine:
                 else:
                     # eval engines never run a data-gradient: no second packed panel (halves their weight copy)
                     self.convs[m] = ConvL(m, self.device, need_dgrad=self.training, training=self.training,
-                                          name=name)
+                                          name=name, arith=self.arith)
             elif isinstance(m, nn.modules.batchnorm._BatchNorm):
                 self.bns[m] = BNL(m, self)
 
@@ -454,28 +515,29 @@ class Engine:
                 sc, sh, relu, res = fold if fold is not None else (None, None, False, None)
                 self._wino_rows(x.data, x.ld, cl.Ci, cl.wino.U_fwd, cl.wino.Co_pad, out.data, out.ld, cl.Co, x.N, x.H,
                                 x.W, cl.dil, T, self._wino_scratch("Vdy", 16 * T * cl.Ci), add=None if res is None else
-                                res.data, ldadd=0 if res is None else res.ld, fold=(sc, sh, relu), split=cl.split)
+                                res.data, ldadd=0 if res is None else res.ld, fold=(sc, sh, relu), arith=cl.arith)
                 return out
             assert fold is None
             V = self.buf((16 * T * cl.Ci,), tag="winoV")      # kept: the weight gradient contracts it with dy
             self._wino_rows(x.data, x.ld, cl.Ci, cl.wino.U_fwd, cl.wino.Co_pad, out.data, out.ld, cl.Co, x.N, x.H, x.W,
-                            cl.dil, T, V, stats=stats, split=cl.split)
+                            cl.dil, T, V, stats=stats, arith=cl.arith)
             if x.fuse_ok:
                 x.pending += 1
             self.push("conv", lambda: self._conv_bwd_wino(x, out, cl, m, V, T), x=x, y=out, cl=cl, m=m)
             return out
-        tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld)
-        ev = self._t0("conv_igemm_kernel<%d,%d,false,%d>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
-        with ops.conv_split(cl.split == 6):
-            if fold is not None:
-                sc, sh, relu, res = fold
-                ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                             bias=sh, scale=sc, relu=relu, add=None if res is None else res.data,
-                             ldadd=0 if res is None else res.ld, scratch=self.scratch())
-            else:
-                ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                             bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats,
-                             nslot=ops.NSLOT, scratch=self.scratch())
+        rs = cl.R * cl.S if cl.R * cl.S in (1, 9) else 0
+        ar = cl.arith if rs else ops.ARITH_F32       # the generic tap walk has no split instance
+        tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld, ar)
+        ev = self._t0("conv_igemm_kernel<%d,%d,false,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
+        if fold is not None:
+            sc, sh, relu, res = fold
+            ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                         bias=sh, scale=sc, relu=relu, add=None if res is None else res.data,
+                         ldadd=0 if res is None else res.ld, scratch=self.scratch(), arith=ar)
+        else:
+            ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                         bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats,
+                         nslot=ops.NSLOT, scratch=self.scratch(), arith=ar)
         self._t1(ev)
         if self.training:
             if x.fuse_ok:
@@ -487,11 +549,11 @@ class Engine:
         dy = y.grad
         flops = 2.0 * y.M * cl.Co * cl.Ci * cl.R * cl.S
         big = cl.Ci % 128 == 0 and cl.Co >= 128
-        # 128 x 128 tiles run the direct-to-LDS kernel (conv_igemm.hip: WGRAD_DMA_POLICY), 64 x 64 the register-staged one
-        ev = self._t0("conv_wgrad_dma_kernel<128x128>+reduce" if big else "conv_wgrad_kernel<64,64>+reduce", flops)
-        with ops.conv_split(cl.split_w):
-            ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
-                           cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil)
+        # 128 x 128 tiles run the direct-to-LDS kernel (conv_igemm.hip: WGRAD_DMA_POLICY) — or, under bf16x3, the SP
+        # instance of the register-staged one — and 64 x 64 tiles the register-staged fp32 kernel
+        ev = self._t0(self._wgrad_family(big, cl.arith), flops)
+        ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
+                       cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil, arith=cl.arith)
         self._t1(ev)
         ready = [m.weight]
         if m.bias is not None:
@@ -503,6 +565,12 @@ class Engine:
             ops.bn_param_grads(st, self._dummy(C4), cl.bgrad, cl.Co)
             ready.append(m.bias)
         self._ready(ready)
+
+    @staticmethod
+    def _wgrad_family(big, arith):
+        if not big:
+            return "conv_wgrad_kernel<64,64>+reduce"
+        return "conv_wgrad_kernel<128,128,SP3>+reduce" if arith == ops.ARITH_BF16X3 else "conv_wgrad_dma_kernel<128x128>+reduce"
 
     def _conv_bwd(self, x, y, cl, m):
         dy = y.grad
@@ -533,18 +601,20 @@ class Engine:
             bs = x.bnsrc
             fuse = (self.fuse_bnr and last and bs is not None and x.C % 4 == 0 and x.ld % 4 == 0 and
                     all(yk.ld % 4 == 0 for yk, _ in bs["bns"]))
-            tile = ops.chosen_tile("dgrad", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, y.ld, x.ld)
-            ev = self._t0("conv_igemm_kernel<%d,%d,true,%d>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, cl.R * cl.S if cl.R * cl.S in (1, 9) else 0), flops)
-            with ops.conv_split(cl.split == 6):
-                if fuse:
-                    ops.conv_dgrad_bnreduce(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                                            x.data if bs["relu"] else None, x.ld,
-                                            [(yk.data, yk.ld, blk.mean, blk.invstd, blk.sums) for yk, blk in bs["bns"]],
-                                            ops.NSLOT, add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
-                    x.bn_reduced = True
-                else:
-                    ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                                   add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch())
+            rs = cl.R * cl.S if cl.R * cl.S in (1, 9) else 0
+            ar = cl.arith if rs else ops.ARITH_F32
+            tile = ops.chosen_tile("dgrad", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, y.ld, x.ld, ar)
+            ev = self._t0("conv_igemm_kernel<%d,%d,true,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)), flops)
+            if fuse:
+                ops.conv_dgrad_bnreduce(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                                        x.data if bs["relu"] else None, x.ld,
+                                        [(yk.data, yk.ld, blk.mean, blk.invstd, blk.sums) for yk, blk in bs["bns"]],
+                                        ops.NSLOT, add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch(),
+                                        arith=ar)
+                x.bn_reduced = True
+            else:
+                ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
+                               add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch(), arith=ar)
             self._t1(ev)
             x.ginit = True
 
@@ -561,7 +631,7 @@ class Engine:
         return t
 
     def _wino_rows(self, src, lds, K, U, rows_pad, dst, ldd, Nout, N, H, W, d, T, V, stats=None, add=None, ldadd=0,
-                   bnr=None, fold=None, split=0):
+                   bnr=None, fold=None, arith=ops.ARITH_F32):
         """input transform -> 16 batched row GEMMs [T x K] x [K x Nout] -> output transform: the forward of a Winograd conv
         (src = x, U = U_fwd) and its data gradient (src = dy, U = the flipped / transposed filter)."""
         px = N * H * W
@@ -569,18 +639,13 @@ class Engine:
         ev = self._t0(WINO_HBM, -4.0 * (px * K + 16 * T * K))
         ops.wino_input_transform(src, lds, V, N, H, W, K, d)
         self._t1(ev)
-        if split == 6 and SPLIT_WINO_KERNEL == "igemm":
-            ev = self._t0("conv_igemm_kernel<SP=3> (experiment)", 2.0 * 16 * T * Nout * K)
-            with ops.conv_split(True):
-                ops.gemm_rows_batched(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16)
-        elif split:
-            ev = self._t0("gemm_rows_bf16split_kernel<%d> (experiment)" % split, 2.0 * 16 * T * Nout * K)
-            ops.gemm_rows_batched_bf16split(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16,
-                                            nsplit=2 if split == 3 else 3)
+        if arith == ops.ARITH_BF16X3 and WINO_BF16X3_KERNEL == "standalone" and K % 16 == 0 and rows_pad % 128 == 0:
+            ev = self._t0("gemm_rows_bf16split_kernel<3,16> (bf16x3)", 2.0 * 16 * T * Nout * K)
+            ops.gemm_rows_batched_bf16split(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16, nsplit=3)
         else:
-            ev = self._t0("conv_igemm_kernel<128,%d,false,1>(+splitk_epilogue)" % (128 if Nout >= 128 else 64),
+            ev = self._t0("conv_igemm_kernel<128,%d,false,1%s>(+splitk_epilogue)" % (128 if Nout >= 128 else 64, _fam(arith)),
                           2.0 * 16 * T * Nout * K)
-            ops.gemm_rows_batched(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16)
+            ops.gemm_rows_batched(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16, arith=arith)
         self._t1(ev)
         ev = self._t0(WINO_HBM, -4.0 * (16 * T * Nout + px * Nout * (1 + (add is not None) + (2 if bnr else 0))))
         if bnr is not None:
@@ -607,9 +672,9 @@ class Engine:
             ev = self._t0(WINO_HBM, -4.0 * (px * cl.Co + 16 * T * cl.Co))
             ops.wino_dy_transform_wgrad(dy, y.ld, Yh, cl.Co, N, H, W, cl.Co, d)
             self._t1(ev)
-            ev = self._t0("conv_wgrad_dma_kernel<128x128>+reduce", gflops)
-            with ops.conv_split(cl.split_w):
-                ops.gemm_kmajor_batched(V, cl.Ci, T * cl.Ci, Yh, cl.Co, T * cl.Co, dU, cl.Co * cl.Ci, scr, T, cl.Ci, cl.Co, 16)
+            ev = self._t0(self._wgrad_family(True, cl.arith), gflops)
+            ops.gemm_kmajor_batched(V, cl.Ci, T * cl.Ci, Yh, cl.Co, T * cl.Co, dU, cl.Co * cl.Ci, scr, T, cl.Ci, cl.Co, 16,
+                                    arith=cl.arith)
             self._t1(ev)
             ev = self._t0(WINO_HBM, -4.0 * 25 * cl.Co * cl.Ci)
             ops.wino_filter_grad(dU, cl.wgrad, cl.Co, cl.Ci)
@@ -639,7 +704,7 @@ class Engine:
                 bnr = (x.data if bs["relu"] else None, x.ld, yk.data, yk.ld, blk.mean, blk.invstd, blk.sums)
             self._wino_rows(dy, y.ld, cl.wino.Kc, cl.wino.U_dgrad, cl.wino.Ci_pad, gx, x.ld, cl.Ci, N, H, W, d, T,
                             self._wino_scratch("Vdy", 16 * T * cl.wino.Kc), add=gx if x.ginit else None, ldadd=x.ld,
-                            bnr=bnr, split=cl.split)
+                            bnr=bnr, arith=cl.arith)
             if bnr is not None:
                 x.bn_reduced = True
             x.ginit = True
@@ -660,8 +725,22 @@ class Engine:
         """256 MB arena for split-K partial slabs (conv fwd/dgrad at small batch, every wgrad), one per stream that
         work is issued on (shared by the engines of the process: work on one stream is ordered)."""
         st = torch.cuda.current_stream(self.device)
-        return _shared(self.device, "scratch@%x" % st.cuda_stream,
-                       lambda: torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device))
+        dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        lru = _SHARED.setdefault((dev, "scratch_lru"), [])      # [(stream handle, arena)], most recently used last
+        for i, (h, t) in enumerate(lru):
+            if h == st.cuda_stream:
+                if i != len(lru) - 1:
+                    lru.append(lru.pop(i))
+                return t
+        # at most MAX_SCRATCH_ARENAS (256 MB each) are kept: the streams the engines themselves use (the caller's, the
+        # high-priority chain) plus a few caller streams; the least recently used one is released after a device
+        # synchronisation (nothing can still be reading it)
+        if len(lru) >= MAX_SCRATCH_ARENAS:
+            torch.cuda.synchronize(self.device)
+            lru.pop(0)
+        t = torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device)
+        lru.append((st.cuda_stream, t))
+        return t
 
     def _t0(self, family, flops):
         if self.ktimer is None:
@@ -1038,34 +1117,18 @@ class Engine:
 
     # Out-of-range class ids: torch's CrossEntropyLoss (the reference's criterion, tool/train.py:121) raises on them; the
     # fused head counts them (acc[2]) and treats them as ignored.  The first step of an engine checks synchronously
-    # (label_check, below); every later step copies the count to pinned host memory behind the head kernel and the NEXT
-    # forward that finds the copy complete raises — no synchronisation on the training path.
-    def _watch_label_count(self, acc):
-        if getattr(self, "_lbl_ev", None) is not None:
-            return                      # an earlier copy is still in flight: look at that one first
-        if not hasattr(self, "_lbl_host"):
-            self._lbl_host = torch.zeros(1, dtype=F64).pin_memory()
-        self._lbl_host.copy_(acc[2:3], non_blocking=True)
-        self._lbl_ev = torch.cuda.Event()
-        self._lbl_ev.record()
-
-    def _poll_label_count(self, wait=False):
-        ev = getattr(self, "_lbl_ev", None)
-        if ev is None:
-            return
-        if wait:
-            ev.synchronize()
-        elif not ev.query():
-            return
-        self._lbl_ev = None
-        nbad = int(self._lbl_host[0].item())
-        if nbad:
-            raise IndexError("Target out of bounds: %d label(s) of an earlier step were neither ignore_index nor in "
-                             "[0, %d) (counted by the fused loss head)" % (nbad, self.model.cls[4].weight.shape[0]))
+    # (label_check, below); EVERY later step copies its count into a ring of pinned host slots behind the head kernel
+    # (LabelWatch, one per model, shared by its engines), and the next forward / Trainer.step / eval forward / explicit
+    # check_labels() that finds copies complete raises — no synchronisation on the training path, no step skipped.
+    def _label_watch(self):
+        w = self.model.__dict__.get("_hip_label_watch")
+        if w is None:
+            w = self.model.__dict__["_hip_label_watch"] = LabelWatch()
+        return w
 
     def check_labels(self):
-        """Blocks until the label count of the last watched step is on the host and raises if it is non-zero."""
-        self._poll_label_count(wait=True)
+        """Blocks until the label counts of all watched steps are on the host and raises if any is non-zero."""
+        self._label_watch().poll(self.model.cls[4].weight.shape[0], wait=True)
 
     def ce_bwd(self, rec, gloss):
         s = rec["scores"]
@@ -1124,6 +1187,8 @@ class Engine:
         return x_tmp, feat
 
     def forward_eval(self, x):
+        # validation is a natural checkpoint for the label counts of the training steps before it (no pending copy: free)
+        self._label_watch().poll(self.model.cls[4].weight.shape[0], wait=True)
         x = self._begin(x)
         x_tmp, feat = self._features(x)
         scores = self.head(feat, self.model.cls, "m")
@@ -1145,7 +1210,7 @@ class Engine:
         y = y.contiguous()
         h, w = self.out_hw()
         assert tuple(y.shape) == (self.N, h, w), "target must be [N,%d,%d]" % (h, w)
-        self._poll_label_count()
+        self._label_watch().poll(self.model.cls[4].weight.shape[0])
         if not self._labels_checked or os.environ.get("SEMSEG_CHECK_LABELS") == "1":
             # torch's CrossEntropyLoss raises on class ids outside [0, C); the fused head would silently ignore
             # them.  Checked on this engine's first step (one sync), every step with SEMSEG_CHECK_LABELS=1.
@@ -1157,7 +1222,7 @@ class Engine:
         x_tmp, feat = self._features(x)
         scores, aux = self.heads_train(feat, x_tmp)
         main_loss, pred, self._rec_main = self.ce(scores, y, h, w, ignore_index, True, "m")
-        self._watch_label_count(self._rec_main["acc"])
+        self._label_watch().watch(self._rec_main["acc"])
         aux_loss, _, self._rec_aux = self.ce(aux, y, h, w, ignore_index, False, "a")
         return pred, main_loss, aux_loss
 

@@ -60,6 +60,13 @@ class HipSegModule(nn.Module):
             cache.pop(next(iter(cache)))      # evict the least recently used shape
         return eng
 
+    def check_labels(self):
+        """Blocks until the out-of-range-label counts of the training steps so far are on the host and raises IndexError if
+        any is non-zero (see semseg_amd.engine.LabelWatch; eval forwards call this implicitly)."""
+        for eng in self.__dict__.get("_engines", {}).values():
+            eng.check_labels()
+            break
+
     def _ignore_index(self):
         crit = getattr(self, "criterion", None)
         ii = getattr(crit, "ignore_index", 255)

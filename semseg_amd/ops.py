@@ -1,8 +1,6 @@
 """Thin tensor-level wrappers over the C ABI (include/semseg_hip.h).  torch is used only for device
 memory and the current HIP stream.  Every wrapper raises on a non-zero return code; nothing here
 computes on the CPU."""
-import contextlib
-
 import torch
 
 from ._lib import lib
@@ -66,6 +64,10 @@ class PackedConv:
 
 NSLOT = 8  # replicas of every fp64 statistics vector (see include/semseg_hip.h)
 
+# Arithmetic of the matrix-core products, a per-launch argument of every GEMM-shaped entry point (include/semseg_hip.h):
+ARITH_F32 = 0      # exact fp32 products (v_mfma_f32_32x32x2_f32)
+ARITH_BF16X3 = 3   # fp32 operands cut into three bf16 pieces in flight, six cross products, fp32 accumulation
+
 # ---------------------------------------------------------------------------------------------
 # Tile width of the forward / data-gradient kernel: a COMMITTED per-shape table.
 # Layers with >= 128 output columns can run 128 x 128 or 128 x 64 tiles on the same packed panels.  Which one wins is
@@ -98,23 +100,37 @@ def load_tile_table(path=TILE_TABLE_PATH):
         return {k: int(v) for k, v in _json.load(f)["tiles"].items()}
 
 
-TILE_CHOICE = load_tile_table()
-# EXPERIMENT: tile shapes measured with the split-bf16 instances of the kernel, keys suffixed "|sp";
-# looked up only inside ops.conv_split(True)
+def _load_tables():
+    """Both committed tables in one dict; a code whose column width exceeds what the packed panels of that layer are padded
+    for (PackedConv: 64 columns for layers with fewer than 128 output columns) would make the kernel read past the
+    panel, so such an entry is dropped here and the shape runs its default."""
+    out = {}
+    for path in (TILE_TABLE_PATH, TILE_TABLE_SP_PATH):
+        for k, v in load_tile_table(path).items():
+            f = k.split("|")
+            ncols = int(f[5]) if f[0] == "fwd" else int(f[4])      # fwd: Co columns, dgrad: Ci columns
+            if v not in TILE_CODES or (ncols < 128 and v % 1000 > 64):
+                continue
+            out[k] = v
+    return out
+
+
+TILE_CODES = (128, 64, 1128, 1064)   # 128x128, 128x64, 64x128, 64x64 (rows x columns; include/semseg_hip.h)
+TILE_TIMES = {}   # key -> {tile code: ms per launch}, filled in tuning mode only
+# tile shapes measured with the SEMSEG_ARITH_BF16X3 instances of the kernels: keys suffixed "|sp"
 TILE_TABLE_SP_PATH = TILE_TABLE_PATH.replace("tile_table.json", "tile_table_sp.json")
-TILE_CHOICE.update(load_tile_table(TILE_TABLE_SP_PATH))
-_SPLIT_ON = False
+TILE_CHOICE = _load_tables()
 
 
-def _tuned_tile(key, dflt, device, out_floats, launch):
-    codes = TILE_CODES if dflt == 128 else (64, 1064)
+def _tuned_tile(key, dflt, device, out_floats, launch, arith=ARITH_F32):
     """Table lookup; with SEMSEG_TILE_TUNE=1 an unknown shape is timed once (launch(tile, out_tensor) -> return code of a
     side-effect-free launch of this shape into a scratch output on the operands' device)."""
-    if _SPLIT_ON:
+    codes = TILE_CODES if dflt == 128 else (64, 1064)
+    if arith == ARITH_BF16X3:
         key = key + "|sp"
     t = TILE_CHOICE.get(key)
     if t is not None:
-        return t
+        return t if (dflt == 128 or t % 1000 == 64) else dflt
     if not TILE_TUNE:
         return dflt
     tmp = torch.empty(out_floats, dtype=torch.float32, device=device)
@@ -139,10 +155,6 @@ def _tuned_tile(key, dflt, device, out_floats, launch):
     return t
 
 
-TILE_CODES = (128, 64, 1128, 1064)   # 128x128, 128x64, 64x128, 64x64 (rows x columns; include/semseg_hip.h)
-TILE_TIMES = {}   # key -> {tile code: ms per launch}, filled in tuning mode only
-
-
 def _scr(scratch):
     return (None, 0) if scratch is None else (scratch.data_ptr(), scratch.numel())
 
@@ -153,63 +165,60 @@ def conv_pack_weights_multi(descs_dev, starts_dev, nconv, total_blocks):
 
 
 def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None, ldadd=0, stats=None,
-             nslot=1, scratch=None, scale=None, relu=False):
+             nslot=1, scratch=None, scale=None, relu=False, arith=ARITH_F32):
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
-    tile = pk.tile_fwd
-    if True:
-        ldt = roundup(pk.Co, 4)
-        tile = _tuned_tile(tile_key("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), tile, x.device,
-                           N * Ho * Wo * ldt,
-                           lambda t, out: lib.semseg_conv_fwd(
-                               _p(x), ldx, _p(pk.w_fwd), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
-                               pad, dil, None, None, 0, None, 0, None, 1, t, *_scr(scratch), _stream()))
+    ldt = roundup(pk.Co, 4)
+    tile = _tuned_tile(tile_key("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), pk.tile_fwd, x.device,
+                       N * Ho * Wo * ldt,
+                       lambda t, out: lib.semseg_conv_fwd(
+                           _p(x), ldx, _p(pk.w_fwd), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
+                           pad, dil, None, None, 0, None, 0, None, 1, t, arith, *_scr(scratch), _stream()), arith)
     _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
                             pk.R, pk.S, stride, pad, dil, _p(bias), _p(scale), int(relu), _p(add), ldadd,
-                            _p(stats), nslot, tile, *_scr(scratch), _stream()), "conv_fwd")
+                            _p(stats), nslot, tile, arith, *_scr(scratch), _stream()), "conv_fwd")
     return Ho, Wo
 
 
-def chosen_tile(kind, pk, N, H, W, stride, pad, dil, ld_in, ld_out):
+def chosen_tile(kind, pk, N, H, W, stride, pad, dil, ld_in, ld_out, arith=ARITH_F32):
     """Tile width the (already measured) shape runs with; kind "fwd" | "dgrad".  For kernel-family labels."""
     dflt = pk.tile_fwd if kind == "fwd" else pk.tile_dgrad
-    return TILE_CHOICE.get(tile_key(kind, N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), dflt)
+    key = tile_key(kind, N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil) + ("|sp" if arith == ARITH_BF16X3 else "")
+    t = TILE_CHOICE.get(key, dflt)
+    return t if (dflt == 128 or t % 1000 == 64) else dflt
 
 
-def _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch):
-    tile = pk.tile_dgrad
-    if True:
-        ldt = roundup(pk.Ci, 4)
-        tile = _tuned_tile(tile_key("dgrad", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), tile, dy.device,
-                           N * H * W * ldt,
-                           lambda t, out: lib.semseg_conv_dgrad(
-                               _p(dy), lddy, _p(pk.w_dgrad), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S,
-                               stride, pad, dil, None, 0, t, *_scr(scratch), _stream()))
-    return tile
+def _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch, arith=ARITH_F32):
+    ldt = roundup(pk.Ci, 4)
+    return _tuned_tile(tile_key("dgrad", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), pk.tile_dgrad, dy.device,
+                       N * H * W * ldt,
+                       lambda t, out: lib.semseg_conv_dgrad(
+                           _p(dy), lddy, _p(pk.w_dgrad), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S,
+                           stride, pad, dil, None, 0, t, arith, *_scr(scratch), _stream()), arith)
 
 
-def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldadd=0, scratch=None):
+def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldadd=0, scratch=None, arith=ARITH_F32):
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
-    tile = _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch)
+    tile = _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch, arith)
     _ck(lib.semseg_conv_dgrad(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo,
-                              pk.Co, pk.R, pk.S, stride, pad, dil, _p(add), ldadd, tile,
+                              pk.Co, pk.R, pk.S, stride, pad, dil, _p(add), ldadd, tile, arith,
                               *_scr(scratch), _stream()), "conv_dgrad")
 
 
 def conv_dgrad_bnreduce(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, act, ldact, bns, nslot, add=None, ldadd=0,
-                        scratch=None):
+                        scratch=None, arith=ARITH_F32):
     """Data gradient fused with the BatchNorm-backward reduction of the layer(s) that produced the conv's input.
     bns: 1 or 2 tuples (y, ldy, mean, invstd, sums[nslot][2*Ci])."""
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
     b0 = bns[0]
     b1 = bns[1] if len(bns) > 1 else (None, 0, None, None, None)
-    tile = _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch)
+    tile = _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch, arith)
     _ck(lib.semseg_conv_dgrad_bnreduce(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R,
                                        pk.S, stride, pad, dil, _p(add), ldadd, tile, len(bns), _p(act), ldact,
                                        _p(b0[0]), b0[1], _p(b0[2]), _p(b0[3]), _p(b0[4]),
-                                       _p(b1[0]), b1[1], _p(b1[2]), _p(b1[3]), _p(b1[4]), nslot, *_scr(scratch),
+                                       _p(b1[0]), b1[1], _p(b1[2]), _p(b1[3]), _p(b1[4]), nslot, arith, *_scr(scratch),
                                        _stream()), "conv_dgrad_bnreduce")
 
 
@@ -276,37 +285,37 @@ def wino_filter_grad(dU, dw, Co, Ci, accumulate=False):
     _ck(lib.semseg_wino_filter_grad(_p(dU), _p(dw), Co, Ci, int(accumulate), _stream()), "wino_filter_grad")
 
 
-def wino_conv_fwd(x, ldx, wc, y, ldy, N, H, W, dil, V, Mbuf, stats=None, nslot=1, add=None, ldadd=0):
+def wino_conv_fwd(x, ldx, wc, y, ldy, N, H, W, dil, V, Mbuf, stats=None, nslot=1, add=None, ldadd=0, arith=ARITH_F32):
     """y[N,H,W,ldy] = conv3x3(x, w; stride 1, padding = dilation = dil).  V [16*T*Ci] receives the transformed input
     (kept by the caller for the weight gradient), Mbuf [>= 16*T*Co] is scratch."""
     T = wino_tiles(N, H, W, dil)
     Ci, Co = wc.Ci, wc.Co
     wino_input_transform(x, ldx, V, N, H, W, Ci, dil)
-    gemm_rows_batched(V, Ci, T * Ci, wc.U_fwd, wc.Co_pad * Ci, Mbuf, Co, T * Co, T, Ci, Co, 16)
+    gemm_rows_batched(V, Ci, T * Ci, wc.U_fwd, wc.Co_pad * Ci, Mbuf, Co, T * Co, T, Ci, Co, 16, arith=arith)
     wino_output_transform(Mbuf, Co, y, ldy, N, H, W, Co, dil, add=add, ldadd=ldadd, stats=stats, nslot=nslot)
     return T
 
 
-def wino_conv_dgrad(dy, lddy, wc, dx, lddx, N, H, W, dil, Vdy, Mbuf, add=None, ldadd=0):
+def wino_conv_dgrad(dy, lddy, wc, dx, lddx, N, H, W, dil, Vdy, Mbuf, add=None, ldadd=0, arith=ARITH_F32):
     """dx[N,H,W,lddx] (= | + add) = the data gradient of the same convolution: a 3x3 convolution of dy with the
     transposed filter, taps rotated by 180 degrees.  dy must be readable (zero) up to Kc = roundup(Co, 32) channels."""
     T = wino_tiles(N, H, W, dil)
     Ci, Kc = wc.Ci, wc.Kc
     assert lddy >= Kc
     wino_input_transform(dy, lddy, Vdy, N, H, W, Kc, dil)
-    gemm_rows_batched(Vdy, Kc, T * Kc, wc.U_dgrad, wc.Ci_pad * Kc, Mbuf, Ci, T * Ci, T, Kc, Ci, 16)
+    gemm_rows_batched(Vdy, Kc, T * Kc, wc.U_dgrad, wc.Ci_pad * Kc, Mbuf, Ci, T * Ci, T, Kc, Ci, 16, arith=arith)
     wino_output_transform(Mbuf, Ci, dx, lddx, N, H, W, Ci, dil, add=add, ldadd=ldadd)
     return T
 
 
-def wino_conv_wgrad(V, dy, lddy, wc, dw, N, H, W, dil, Yh, dU, scratch, accumulate=False):
+def wino_conv_wgrad(V, dy, lddy, wc, dw, N, H, W, dil, Yh, dU, scratch, accumulate=False, arith=ARITH_F32):
     """dw[Co][Ci][3][3] from the kept transformed input V and dy.  Yh [16*T*roundup(Co,128)] zero-initialised scratch
     (its padding columns must stay zero), dU [16*Co*Ci] scratch."""
     T = wino_tiles(N, H, W, dil)
     Ci, Co = wc.Ci, wc.Co
     ldo = roundup(Co, 128)
     wino_dy_transform_wgrad(dy, lddy, Yh, ldo, N, H, W, roundup(Co, 4), dil)
-    gemm_kmajor_batched(V, Ci, T * Ci, Yh, ldo, T * ldo, dU, Co * Ci, scratch, T, Ci, Co, 16)
+    gemm_kmajor_batched(V, Ci, T * Ci, Yh, ldo, T * ldo, dU, Co * Ci, scratch, T, Ci, Co, 16, arith=arith)
     wino_filter_grad(dU, dw, Co, Ci, accumulate)
 
 
@@ -315,11 +324,11 @@ def wgrad_scratch_floats(Ci, Co, R, S):
 
 
 def conv_wgrad(x, ldx, dy, lddy, dw, scratch, N, H, W, Ci, Co, R, S, stride, pad, dil,
-               accumulate=False):
+               accumulate=False, arith=ARITH_F32):
     Ho = conv_out(H, R, stride, pad, dil)
     Wo = conv_out(W, S, stride, pad, dil)
     _ck(lib.semseg_conv_wgrad(_p(x), ldx, _p(dy), lddy, _p(dw), _p(scratch), scratch.numel(), N, H,
-                              W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, int(accumulate), _stream()),
+                              W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, int(accumulate), arith, _stream()),
         "conv_wgrad")
 
 
@@ -511,54 +520,39 @@ def transpose_batched(inp, ldi, bsi, out, ldo, bso, batch, R, C):
         "transpose_batched")
 
 
-def gemm_rows(a_ptr, lda, bt_ptr, c_ptr, ldc, M, K, Nout, add_ptr=None, ldadd=0):
+def gemm_rows(a_ptr, lda, bt_ptr, c_ptr, ldc, M, K, Nout, add_ptr=None, ldadd=0, arith=ARITH_F32):
     """C[M][Nout] = A[M][K] * B, B given K-contiguous as bt[Nout_pad][K] (K % 32 == 0): the 1x1
     implicit-GEMM kernel on raw device pointers."""
     tile = 128 if Nout >= 128 else 64
     _ck(lib.semseg_conv_fwd(a_ptr, lda, bt_ptr, c_ptr, ldc, 1, M, 1, K, M, 1, Nout, 1, 1, 1, 0, 1, None,
-                            None, 0, add_ptr, ldadd, None, 1, tile, None, 0, _stream()), "gemm_rows")
+                            None, 0, add_ptr, ldadd, None, 1, tile, arith, None, 0, _stream()), "gemm_rows")
 
 
-def gemm_kmajor(x_ptr, ldx, y_ptr, ldy, out_ptr, scratch, K, Ci, Co, accumulate=False):
+def gemm_kmajor(x_ptr, ldx, y_ptr, ldy, out_ptr, scratch, K, Ci, Co, accumulate=False, arith=ARITH_F32):
     """out[Co][Ci] (=|+=) sum_k y[k][co] * x[k][ci] — the weight-gradient kernel as a K-major GEMM."""
     _ck(lib.semseg_conv_wgrad(x_ptr, ldx, y_ptr, ldy, out_ptr, _p(scratch), scratch.numel(), 1, K, 1, Ci,
-                              K, 1, Co, 1, 1, 1, 0, 1, int(accumulate), _stream()), "gemm_kmajor")
+                              K, 1, Co, 1, 1, 1, 0, 1, int(accumulate), arith, _stream()), "gemm_kmajor")
 
 
-def gemm_rows_batched(a, lda, a_bs, bt, bt_bs, c, ldc, c_bs, M, K, Nout, batch):
+def gemm_rows_batched(a, lda, a_bs, bt, bt_bs, c, ldc, c_bs, M, K, Nout, batch, arith=ARITH_F32):
     """C[b][M][Nout] = A[b][M][K] * Bt[b][Nout_pad][K]^T in ONE launch (tensors or raw pointers; strides in floats)."""
-    _ck(lib.semseg_gemm_rows_batched(_ptr(a), lda, a_bs, _ptr(bt), bt_bs, _ptr(c), ldc, c_bs, M, K, Nout, batch,
+    _ck(lib.semseg_gemm_rows_batched(_ptr(a), lda, a_bs, _ptr(bt), bt_bs, _ptr(c), ldc, c_bs, M, K, Nout, batch, arith,
                                      _stream()), "gemm_rows_batched")
 
 
-@contextlib.contextmanager
-def conv_split(on):
-    """EXPERIMENT: inside the block the 1x1 / GEMM instances of conv_fwd, conv_dgrad(_bnreduce) and
-    gemm_rows(_batched) form their products from three-way split bf16 pieces (process-wide host switch, read at launch)."""
-    if not on:
-        yield
-        return
-    global _SPLIT_ON
-    old = int(lib.semseg_experiment_conv_split(3))
-    was, _SPLIT_ON = _SPLIT_ON, True
-    try:
-        yield
-    finally:
-        _SPLIT_ON = was
-        lib.semseg_experiment_conv_split(old)
-
-
-def gemm_rows_batched_bf16split(a, lda, a_bs, bt, bt_bs, c, ldc, c_bs, M, K, Nout, batch, nsplit=2, bk=16):
-    """EXPERIMENT: gemm_rows_batched with the fp32 operands split into nsplit bf16 pieces in flight and multiplied on the
-    bf16 matrix-core instruction (csrc/gemm_bf16split.hip).  Bt rows must be readable up to roundup(Nout, 128)."""
+def gemm_rows_batched_bf16split(a, lda, a_bs, bt, bt_bs, c, ldc, c_bs, M, K, Nout, batch, nsplit=3, bk=16):
+    """gemm_rows_batched on the split-bf16 kernel of csrc/gemm_bf16split.hip: nsplit 3 = ARITH_BF16X3 (what the engine runs
+    for the Winograd GEMMs); nsplit 2 (two pieces, three products) is a measurement only and fails the per-op parity
+    criteria.  Bt rows must be readable up to roundup(Nout, 128)."""
     _ck(lib.semseg_gemm_rows_batched_bf16split(_ptr(a), lda, a_bs, _ptr(bt), bt_bs, _ptr(c), ldc, c_bs, M, K, Nout,
                                                batch, nsplit, bk, _stream()), "gemm_rows_batched_bf16split")
 
 
-def gemm_kmajor_batched(x, ldx, x_bs, y, ldy, y_bs, out, out_bs, scratch, K, Ci, Co, batch, accumulate=False):
+def gemm_kmajor_batched(x, ldx, x_bs, y, ldy, y_bs, out, out_bs, scratch, K, Ci, Co, batch, accumulate=False,
+                        arith=ARITH_F32):
     """out[b][Co][Ci] (=|+=) sum_k y[b][k][co] * x[b][k][ci] in ONE launch of the weight-gradient kernel."""
     _ck(lib.semseg_gemm_kmajor_batched(_ptr(x), ldx, x_bs, _ptr(y), ldy, y_bs, _ptr(out), out_bs, _p(scratch),
-                                       scratch.numel(), K, Ci, Co, int(accumulate), batch, _stream()),
+                                       scratch.numel(), K, Ci, Co, int(accumulate), batch, arith, _stream()),
         "gemm_kmajor_batched")
 
 

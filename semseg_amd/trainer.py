@@ -140,4 +140,14 @@ class Trainer:
         ops.sgd_step(self.flat_w[self.split:], e.flat_grad[self.split:], self.flat_m[self.split:], n2,
                      lr * 10.0, self.momentum, self.wd, gs, first)
         self.steps += 1
+        # label counts of earlier steps that have reached the host by now (non-blocking; see Engine.LabelWatch)
+        e._label_watch().poll(self.model.cls[4].weight.shape[0])
         return pred, main_loss, aux_loss
+
+    def check_labels(self):
+        """Blocks until the out-of-range-label counts of every step so far are on the host; raises IndexError if a step
+        saw a label that is neither ignore_index nor a class id (torch's CrossEntropyLoss, tool/train.py:121, raises on
+        such a batch immediately; here the fused head counts them and the error surfaces at most RING steps later or at
+        this call — call it at epoch end and before validation)."""
+        for e in self.engines.values():
+            e.check_labels()

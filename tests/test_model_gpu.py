@@ -332,8 +332,29 @@ def test_out_of_range_labels_raise_like_torch(report):
     m(x, y2)
     with pytest.raises(IndexError):
         eng.check_labels()                    # explicit, blocking form
-    report("out-of-range label raises IndexError (first step: at once; later steps: at the next forward); "
-           "ignore_index passes")
+    # a bad batch followed by good ones with the host running ahead of the device — every step's count is kept
+    # in the ring (round 3 dropped a step's watch while an earlier copy was still in flight) and surfaces exactly once:
+    # at one of the following forwards or, at the latest, at the blocking check of the module
+    raised = 0
+    m(x, y2)
+    for _ in range(4):
+        try:
+            m(x, y)
+        except IndexError:
+            raised += 1
+    try:
+        m.check_labels()
+    except IndexError:
+        raised += 1
+    assert raised == 1
+    m.eval()
+    m.train()
+    m(x, y2)
+    m.eval()
+    with pytest.raises(IndexError):
+        m(x)                                  # validation forward: the implicit blocking check
+    report("out-of-range label raises IndexError (first step: at once; later steps: at the next forward / check_labels / "
+           "eval forward, none skipped); ignore_index passes")
 
 
 def test_trainer_detects_broken_parameter_aliasing(report):

@@ -862,13 +862,13 @@ def test_gemm_kmajor_batched_chunks_when_scratch_is_small(report):
 
 
 @pytest.mark.parametrize("nsplit,bk", [(2, 16), (2, 32), (3, 16)])
-def test_gemm_rows_bf16split_experiment(nsplit, bk, report):
-    """EXPERIMENT (off by default): the split-bf16 row GEMM against fp64 and next to the fp32
-    matrix-core kernel on the same operands — ragged last row tile, a column tile that is half padding, strided A and C,
-    batch strides.  Bounds from the error model: three pieces / six products carry 24 mantissa bits (rms within 2x of
-    the fp32 kernel's own rounding noise + 1e-7); two pieces / three products carry 16 (rms <= 1e-5)."""
-    from semseg_amd import ops, engine
-    assert engine.SPLIT_BF16 == int(os.environ.get("SEMSEG_SPLIT_BF16", "0"))     # the flag is opt-in
+def test_gemm_rows_bf16split(nsplit, bk, report):
+    """The split-bf16 row GEMM of the Winograd path (csrc/gemm_bf16split.hip; nsplit 3 = SEMSEG_ARITH_BF16X3, DESIGN.md
+    section 8.4) against fp64 and next to the fp32 matrix-core kernel on the same operands — ragged last row tile, a
+    column tile that is half padding, strided A and C, batch strides.  Bounds from the error model: three pieces / six
+    products carry 24 mantissa bits (rms within 2x of the fp32 kernel's own rounding noise + 1e-7); two pieces / three
+    products (a measurement only, nothing in the engine selects it) carry 16 (rms <= 1e-5)."""
+    from semseg_amd import ops
     B, M, K, Nout, lda, ldc = 3, 300, 1024, 192, 1024 + 64, 192 + 64
     g = torch.Generator().manual_seed(17 + nsplit + bk)
     a = torch.randn(B, M, lda, generator=g)
@@ -891,8 +891,8 @@ def test_gemm_rows_bf16split_experiment(nsplit, bk, report):
 
 
 @pytest.mark.parametrize("code", [128, 64, 1128, 1064])
-def test_conv_split_mode_1x1_experiment(code, report, monkeypatch):
-    """EXPERIMENT: the SP instances of the forward / data-gradient kernel (three-way split bf16
+def test_conv_arith_bf16x3_1x1(code, report, monkeypatch):
+    """SEMSEG_ARITH_BF16X3 per launch: the SP instances of the forward / data-gradient kernel (three-way split bf16
     pieces, six bf16 matrix-core products) on a 1x1 conv with every fused epilogue — forward with batch statistics, data
     gradient with residual add, data gradient with the fused BatchNorm-backward reduction — next to the fp32 instances
     on the same operands: rms error within 2x of the fp32 kernel's (+1e-7), statistics and reduction sums to 1e-6."""
@@ -914,13 +914,14 @@ def test_conv_split_mode_1x1_experiment(code, report, monkeypatch):
     rms = lambda a, ref: float((a.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     res = {}
     for split in (False, True):
-        with ops.conv_split(split):
-            yb = torch.empty(N, H, W, Co, device=DEV)
-            stats = torch.zeros(ops.NSLOT * 2 * Co, dtype=torch.float64, device=DEV)
-            ops.conv_fwd(xd, Ci, pk, yb, Co, N, H, W, 1, 0, 1, stats=stats, nslot=ops.NSLOT,
-                         scratch=torch.empty(1 << 24, device=DEV))
-            dxb = torch.empty(N, H, W, Ci, device=DEV)
-            ops.conv_dgrad(dyd, Co, pk, dxb, Ci, N, H, W, 1, 0, 1, add=addd, ldadd=Ci, scratch=torch.empty(1 << 24, device=DEV))
+        ar = ops.ARITH_BF16X3 if split else ops.ARITH_F32
+        yb = torch.empty(N, H, W, Co, device=DEV)
+        stats = torch.zeros(ops.NSLOT * 2 * Co, dtype=torch.float64, device=DEV)
+        ops.conv_fwd(xd, Ci, pk, yb, Co, N, H, W, 1, 0, 1, stats=stats, nslot=ops.NSLOT,
+                     scratch=torch.empty(1 << 24, device=DEV), arith=ar)
+        dxb = torch.empty(N, H, W, Ci, device=DEV)
+        ops.conv_dgrad(dyd, Co, pk, dxb, Ci, N, H, W, 1, 0, 1, add=addd, ldadd=Ci, scratch=torch.empty(1 << 24, device=DEV),
+                       arith=ar)
         torch.cuda.synchronize()
         st = stats.view(ops.NSLOT, 2 * Co).sum(0).cpu()
         res[split] = (rms(nchw(yb).cpu(), y64), rms(nchw(dxb).cpu(), dx64),
@@ -930,13 +931,14 @@ def test_conv_split_mode_1x1_experiment(code, report, monkeypatch):
            % (code, res[True][0], res[False][0], res[True][1], res[False][1], res[True][2], res[True][3]))
     assert res[True][0] <= 2 * res[False][0] + 1e-7 and res[True][1] <= 2 * res[False][1] + 1e-7
     assert res[True][2] < 1e-6 and res[True][3] < 1e-6
-    assert int(ops.lib.semseg_experiment_conv_split(0)) == 0      # the context manager restored the switch
+    with pytest.raises(ops.HipError):                             # an unknown arithmetic code is rejected, not ignored
+        ops.conv_fwd(xd, Ci, pk, yb, Co, N, H, W, 1, 0, 1, arith=6)
 
 
 @pytest.mark.parametrize("case", [(2, 23, 21, 256, 128, 1, 1, 0, 1), (2, 19, 17, 128, 256, 3, 1, 2, 2), (2, 21, 21, 256, 256, 1, 2, 0, 1),
                                   (1, 33, 33, 128, 128, 3, 1, 1, 1)])
-def test_conv_wgrad_split_mode_experiment(case, report, monkeypatch):
-    """EXPERIMENT: the SP instance of the 128 x 128 weight-gradient kernel (pixel-contiguous bf16
+def test_conv_wgrad_arith_bf16x3(case, report, monkeypatch):
+    """SEMSEG_ARITH_BF16X3 per launch: the SP instance of the 128 x 128 weight-gradient kernel (pixel-contiguous bf16
     piece planes, six bf16 matrix-core products) in its three gather modes (1x1, "same" 3x3 with dilation, strided)
     next to the fp32 kernels on the same operands, against fp64: rms within 2x of the fp32 path's (+1e-7)."""
     from semseg_amd import ops
@@ -953,8 +955,8 @@ def test_conv_wgrad_split_mode_experiment(case, report, monkeypatch):
     errs = []
     for split in (False, True):
         dw = torch.full((Co, Ci, k, k), float("nan"), device=DEV)
-        with ops.conv_split(split):
-            ops.conv_wgrad(xd, Ci, dyd, Co, dw, scratch, N, H, W, Ci, Co, k, k, s_, p_, d)
+        ops.conv_wgrad(xd, Ci, dyd, Co, dw, scratch, N, H, W, Ci, Co, k, k, s_, p_, d,
+                       arith=ops.ARITH_BF16X3 if split else ops.ARITH_F32)
         torch.cuda.synchronize()
         errs.append(rms(dw))
     report("conv_wgrad split mode %s: rms %.2e (fp32 path %.2e)" % (case, errs[1], errs[0]))
@@ -962,8 +964,8 @@ def test_conv_wgrad_split_mode_experiment(case, report, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [(3, 13, 11, 128, 128, 3, 1, 2, 2), (2, 21, 21, 128, 256, 3, 2, 1, 1)])
-def test_conv_split_mode_3x3_experiment(case, report):
-    """EXPERIMENT: the SP instances of the 3x3 (unrolled-tap) forward / data-gradient kernel, dilated
+def test_conv_arith_bf16x3_3x3(case, report):
+    """SEMSEG_ARITH_BF16X3 per launch: the SP instances of the 3x3 (unrolled-tap) forward / data-gradient kernel, dilated
     and strided, next to the fp32 instances against fp64: rms within 2x (+1e-7)."""
     from semseg_amd import ops
     N, H, W, Ci, Co, k, s_, p_, d = case
@@ -980,11 +982,11 @@ def test_conv_split_mode_3x3_experiment(case, report):
     rms = lambda a, ref: float((a.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     res = {}
     for split in (False, True):
-        with ops.conv_split(split):
-            yb = torch.empty(N, Ho, Wo, Co, device=DEV)
-            ops.conv_fwd(xd, Ci, pk, yb, Co, N, H, W, s_, p_, d, scratch=torch.empty(1 << 24, device=DEV))
-            dxb = torch.empty(N, H, W, Ci, device=DEV)
-            ops.conv_dgrad(dyd, Co, pk, dxb, Ci, N, H, W, s_, p_, d, scratch=torch.empty(1 << 24, device=DEV))
+        ar = ops.ARITH_BF16X3 if split else ops.ARITH_F32
+        yb = torch.empty(N, Ho, Wo, Co, device=DEV)
+        ops.conv_fwd(xd, Ci, pk, yb, Co, N, H, W, s_, p_, d, scratch=torch.empty(1 << 24, device=DEV), arith=ar)
+        dxb = torch.empty(N, H, W, Ci, device=DEV)
+        ops.conv_dgrad(dyd, Co, pk, dxb, Ci, N, H, W, s_, p_, d, scratch=torch.empty(1 << 24, device=DEV), arith=ar)
         torch.cuda.synchronize()
         res[split] = (rms(nchw(yb).cpu(), y64), rms(nchw(dxb).cpu(), dx64))
     report("conv 3x3 split mode %s: forward rms %.2e (fp32 %.2e)  data gradient %.2e (fp32 %.2e)"
