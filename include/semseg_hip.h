@@ -207,6 +207,25 @@ int semseg_bn_bwd_apply(const float* g, int ldg, const float* y, int ldy, const 
 int semseg_bn_param_grads(double* sums, int nslot, float* dgamma, float* dbeta, int C,
                           int accumulate, double* folded, hipStream_t stream);
 
+/* ---- SyncBN statistics exchange through peer-mapped memory (csrc/xchg.hip; nn.SyncBatchNorm, tool/train.py:142): the
+ * all-reduce of a small fp64 vector among the <= 8 GPUs of one node in ONE kernel per rank.  Every rank owns a buffer of
+ * semseg_xchg_buffer_bytes(world) bytes in fine-grained device memory (semseg_xchg_alloc), exports it
+ * (hipIpcMemHandle_t, 64 bytes) and maps every peer's (semseg_xchg_ipc_import); peer_bases = HOST array of the `world`
+ * mapped base pointers in rank order (own buffer at [rank]).  allreduce: out[0:n] = sum over ranks of (sum over the nslot
+ * replicas of in[nslot][n]), summed in rank order on every rank (bit-identical results); seq = 1, 2, ... must advance by
+ * one per call, identically on every rank; n <= SEMSEG_XCHG_MAX_DOUBLES.  A rank whose peers do not arrive within ~1 s sets
+ * *err_dev = 1 and returns garbage in out (the caller checks err_dev).  OPT-IN path: verified with several processes on
+ * one GPU only (round 4), RCCL stays the default exchange. */
+#define SEMSEG_XCHG_MAX_DOUBLES 16384
+size_t semseg_xchg_buffer_bytes(int world);
+int semseg_xchg_alloc(int world, void** ptr);
+int semseg_xchg_free(void* ptr);
+int semseg_xchg_ipc_export(void* ptr, void* handle64);
+int semseg_xchg_ipc_import(const void* handle64, void** ptr);
+int semseg_xchg_ipc_close(void* ptr);
+int semseg_xchg_allreduce_f64(const double* in, int nslot, int n, double* out, void* const* peer_bases, int world, int rank,
+                              unsigned long long seq, int* err_dev, hipStream_t stream);
+
 /* ---- spatial ops: MaxPool2d(3,2,1) model/resnet.py:115; AdaptiveAvgPool2d model/pspnet.py:14;
  * F.interpolate(bilinear, align_corners=True) model/pspnet.py:25,95,100; model/psanet.py:61,78,97. */
 int semseg_maxpool3x3s2_fwd(const float* x, float* y, uint32_t* idx, int N, int H, int W, int C,

@@ -4,8 +4,9 @@ time the four tile shapes (128 x 128, 128 x 64, 64 x 128, 64 x 64) on real opera
 interleaved rounds of 3 launches, device idle) and keep 128 x 128 unless another shape wins by >= 3 %.  The table is committed; nothing times tiles at run time.
 
     SEMSEG_TILE_TUNE=1 python scripts/make_tile_table.py [out.json]        (GPU box; copy the result into semseg_amd/)
-    ... make_tile_table.py --split [out.json]   the same for the split-bf16 experiment's kernel instances (keys "...|sp",
-                                                semseg_amd/tile_table_sp.json; PSPNet-101 473^2 bs 16 / 2 and PSANet-101 bs 16)
+    ... make_tile_table.py --split [out.json]   the same for the SEMSEG_ARITH_BF16X3 kernel instances (keys "...|sp",
+                                                semseg_amd/tile_table_sp.json; every configuration above) — the engine default
+    (without --split the engines are built with exact fp32 arithmetic: the table of the SEMSEG_ARITH=f32 path)
 """
 import json
 import os
@@ -25,14 +26,10 @@ if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if a != "--split"]
     SPLIT = "--split" in sys.argv[1:]
     out = args[0] if args else os.path.join(ROOT, "gpurun_out", "tile_table_sp.json" if SPLIT else "tile_table.json")
-    if SPLIT:
-        from semseg_amd import engine as E
-        E.SPLIT_BF16, E.SPLIT_LAYERS = 6, ["all"]
-        CONFIGS = [("psp", 101, 473, 150, 16), ("psp", 101, 473, 150, 2), ("psa", 101, 465, 150, 16)]
-        for k in [k for k in ops.TILE_CHOICE if k.endswith("|sp")]:
-            del ops.TILE_CHOICE[k]
-    else:
-        ops.TILE_CHOICE.clear()      # measure everything afresh
+    from semseg_amd import engine as E
+    E.set_arith("bf16x3" if SPLIT else "f32")
+    for k in [k for k in ops.TILE_CHOICE if k.endswith("|sp") == SPLIT]:      # measure everything of this table afresh
+        del ops.TILE_CHOICE[k]
     for arch, layers, size, classes, bs in CONFIGS:
         torch.manual_seed(0)
         if arch == "psp":

@@ -24,6 +24,9 @@ constexpr int BK = 32;   // K-step (floats)
 constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 conflict-free
 
 constexpr int CONV_OCC = 2;   // resident workgroups per CU the forward / data-gradient kernel is compiled for
+#ifndef SP_PIPE
+#define SP_PIPE 1      // bf16x3 direct-to-LDS weight gradient: 0 = read -> split -> MFMA in sequence inside a stage (A/B builds)
+#endif
 
 // exact n / d for 0 <= n < 2^31 by one 64-bit multiply: q = (n * mul) >> sh
 struct FastDiv {
@@ -111,8 +114,76 @@ __device__ __forceinline__ void decode_tile(const ConvArgs& p, int tile, int& ti
   }
 }
 
+// Fused BatchNorm-backward reduction of one 64-row x 32-column block of a wave (the block sits transposed in the wave's
+// LDS slab `wl`): g = (acc (+ add)) * (act > 0) is stored and sum g, sum g * xhat accumulate per lane column in fp32 (`bs`,
+// 8 rows per lane; fp64 across lanes / workgroups afterwards) for one or two BatchNorm layers sharing g.
+// Shape of the loop: the operand tiles (ReLU mask, pre-BN tensor(s), residual gradient) are HBM /
+// L2 reads with ~1-2 us of latency under load, and round 2-3 issued them one row group at a time (16 dependent round trips
+// per wave and tile: the family sat at 0.59 of peak, bound by its epilogue in either arithmetic).  Here the loads of FOUR
+// row groups are issued back to back before the first is used (2 round trips per block), and the loop exists once per
+// (residual add, second BatchNorm) combination, so that absent operands are not loaded at all (round 2-3 aliased them to a
+// present one: 4 loads per row where the two common cases need 2 and 3).  The registers come from the K loop's staging
+// and second-level accumulators, which are dead here; the outer loop is NOT unrolled so that the compiler cannot hoist
+// all eight row groups (223 VGPRs when it did).  Out-of-range rows / columns load from a clamped address and are dropped
+// at the store.
+#ifndef BNR_GROUP
+#define BNR_GROUP 4      // row groups whose operand loads are in flight together (1 = the round-3 loop shape; A/B builds)
+#endif
+template <bool HAS_ADD, bool TWO>
+__device__ __forceinline__ void bnr_rows(const ConvArgs& p, const float* wl, float* dst, int ldd, int mrow0, int colmax,
+                                         int mb, int cg, int c4, int lane, const float* add_in, const f32x4 (&bmu)[2],
+                                         const f32x4 (&bis)[2], float (&bs)[2][8]) {
+  constexpr int G = BNR_GROUP;
+  const bool has_mask = p.bnr_mask != nullptr;
+  const float* maskp = has_mask ? p.bnr_mask : p.bnr_y[0];     // no ReLU: any readable tile, neutralised below
+  const int ldmp = has_mask ? p.bnr_ldm : p.bnr_ldy[0];
+  const int cc = cg < colmax ? cg : 0;
+#pragma nounroll
+  for (int hb = 0; hb < 8 / G; ++hb) {
+    f32x4 aa[G], y0[G], dd[HAS_ADD ? G : 1], y1[TWO ? G : 1];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int m = mb + (lane >> 3) + 8 * (hb * G + q);
+      const size_t mm = (size_t)(m < p.M ? m : p.M - 1);
+      aa[q] = *reinterpret_cast<const f32x4*>(maskp + mm * ldmp + cc);
+      y0[q] = *reinterpret_cast<const f32x4*>(p.bnr_y[0] + mm * p.bnr_ldy[0] + cc);
+      if constexpr (HAS_ADD) dd[q] = *reinterpret_cast<const f32x4*>(add_in + mm * p.ldadd + cc);
+      if constexpr (TWO) y1[q] = *reinterpret_cast<const f32x4*>(p.bnr_y[1] + mm * p.bnr_ldy[1] + cc);
+    }
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int lr = (lane >> 3) + 8 * (hb * G + q);
+      const int m = mb + lr;
+      const bool ok = m < p.M && cg < colmax;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&wl[lr * LDK + c4]);
+      if constexpr (HAS_ADD) v += dd[q];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = ((!has_mask || aa[q][k] > 0.f) && ok) ? v[k] : 0.f;
+      const f32x4 xh0 = (y0[q] - bmu[0]) * bis[0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bs[0][k] += v[k];
+        bs[0][4 + k] = fmaf(v[k], xh0[k], bs[0][4 + k]);
+      }
+      if constexpr (TWO) {
+        const f32x4 xh1 = (y1[q] - bmu[1]) * bis[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bs[1][k] += v[k];
+          bs[1][4 + k] = fmaf(v[k], xh1[k], bs[1][4 + k]);
+        }
+      }
+      if (ok) *reinterpret_cast<f32x4*>(dst + (size_t)(m - mrow0) * ldd + cg) = v;
+    }
+  }
+}
+
 // ---- epilogue shared by the register-staged and the direct-to-LDS kernels ----
-template <int BM, int BN>
+// STATS: the fp64 per-channel statistics of the forward epilogue exist (forward kernels); data-gradient kernels never take
+// statistics, and dropping the per-element fp64 conversion / accumulation from them is ~190 fp64 VALU ops per lane and block
+// BNR: the fused BatchNorm-backward reduction is compiled in (data-gradient kernels only: in the forward kernels it was dead
+// code that cost them ~30 VGPRs and, under bf16x3, 5 % of their time)
+template <int BM, int BN, bool STATS = true, bool BNR = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2][BN / 64], float* smem, bool split,
                                               int ks, int m0, int n0, int tile_m, double* red2, float* y_out,
                                               const float* add_in) {
@@ -135,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
   const bool wide = split || ((p.ldy & 3) == 0 && p.ldy >= Nout4 && (!add_in || (p.ldadd & 3) == 0));
   float* wl = smem + wave * (64 * LDK);              // this wave's slab (needs >= NT/64 * 64 * LDK floats)
   double* red = reinterpret_cast<double*>(smem);     // [BM/64 (wm)][BN][2], used after the stores
-  const bool bnr = !split && p.bnr_n > 0;            // fused BatchNorm-backward reduction (wide stores only)
+  const bool bnr = BNR && !split && p.bnr_n > 0;     // fused BatchNorm-backward reduction (wide stores only)
   double st1[NREP], st2[NREP];
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
@@ -171,56 +242,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
           const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
           const float v = acc[i][j][e] * sv + bv;
           wl[lr * LDK + l31] = v;
-          if (m0 + wm * 64 + lr < p.M && cok) {
-            const double dv = (double)v;
-            s1 += dv;
-            s2 += dv * dv;
+          if constexpr (STATS) {
+            if (m0 + wm * 64 + lr < p.M && cok) {
+              const double dv = (double)v;
+              s1 += dv;
+              s2 += dv * dv;
+            }
           }
         }
       // same-wave LDS traffic is ordered: no barrier needed between the writes above and these reads
       if (bnr) {
-        // Fused BatchNorm-backward reduction.  One row per iteration, its five operand loads issued together and the
-        // loop NOT unrolled: guarded per-operand loads cost up to three dependent HBM round trips per row (+22 % on the
-        // K = 256 data gradients), while unrolling lets the compiler hoist the loads of several rows and grow the
-        // kernel from 159 to 223 VGPRs (residency 3 -> 2, and no room beside the weight-gradient workgroups).
-        // Out-of-range rows / columns load from a clamped address and are dropped at the store; absent operands (no
-        // residual add, no second BatchNorm, no ReLU mask) alias a present one and are neutralised arithmetically.
-        const bool has_add = add_in != nullptr, has_mask = p.bnr_mask != nullptr, two = p.bnr_n > 1;
-        const float* addp = has_add ? add_in : p.bnr_y[0];
-        const int ldap = has_add ? p.ldadd : p.bnr_ldy[0];
-        const float addw = has_add ? 1.f : 0.f;
-        const float* maskp = has_mask ? p.bnr_mask : p.bnr_y[0];
-        const int ldmp = has_mask ? p.bnr_ldm : p.bnr_ldy[0];
-        const float* y1p = two ? p.bnr_y[1] : p.bnr_y[0];
-        const int ldy1 = two ? p.bnr_ldy[1] : p.bnr_ldy[0];
         const int c4 = (lane & 7) * 4;
         const int cg = n0 + wn * (BN / 2) + j * 32 + c4;
-        const int cc = cg < colmax ? cg : 0;
-#pragma nounroll
-        for (int h = 0; h < 8; ++h) {
-          const int lr = (lane >> 3) + 8 * h;
-          const int m = m0 + wm * 64 + lr;
-          const bool ok = m < p.M && cg < colmax;
-          const size_t mm = (size_t)(m < p.M ? m : p.M - 1);
-          const f32x4 vv = *reinterpret_cast<const f32x4*>(&wl[lr * LDK + c4]);
-          const f32x4 aa = *reinterpret_cast<const f32x4*>(maskp + mm * ldmp + cc);
-          const f32x4 dd = *reinterpret_cast<const f32x4*>(addp + mm * ldap + cc);
-          const f32x4 y0 = *reinterpret_cast<const f32x4*>(p.bnr_y[0] + mm * p.bnr_ldy[0] + cc);
-          const f32x4 y1 = *reinterpret_cast<const f32x4*>(y1p + mm * ldy1 + cc);
-          f32x4 v = vv + addw * dd;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = ((!has_mask || aa[k] > 0.f) && ok) ? v[k] : 0.f;
-          const f32x4 xh0 = (y0 - bmu[0]) * bis[0];
-          const f32x4 xh1 = (y1 - bmu[1]) * bis[1];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            bs[0][k] += v[k];
-            bs[0][4 + k] = fmaf(v[k], xh0[k], bs[0][4 + k]);
-            bs[1][k] += v[k];
-            bs[1][4 + k] = fmaf(v[k], xh1[k], bs[1][4 + k]);
-          }
-          if (ok) *reinterpret_cast<f32x4*>(dst + (size_t)(m - mrow0) * ldd + cg) = v;
-        }
+        const int mb = m0 + wm * 64;
+        const bool has_add = add_in != nullptr, two = p.bnr_n > 1;
+        // one specialised copy of the row loop per (residual add, second BatchNorm) combination: a wave-uniform switch
+        // outside the loop instead of aliased or guarded loads inside it
+        if (has_add && two) bnr_rows<true, true>(p, wl, dst, ldd, mrow0, colmax, mb, cg, c4, lane, add_in, bmu, bis, bs);
+        else if (has_add) bnr_rows<true, false>(p, wl, dst, ldd, mrow0, colmax, mb, cg, c4, lane, add_in, bmu, bis, bs);
+        else if (two) bnr_rows<false, true>(p, wl, dst, ldd, mrow0, colmax, mb, cg, c4, lane, add_in, bmu, bis, bs);
+        else bnr_rows<false, false>(p, wl, dst, ldd, mrow0, colmax, mb, cg, c4, lane, add_in, bmu, bis, bs);
       } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -262,9 +303,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
           const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
           if (m < p.M && cok) {
             float v = acc[i][j][e] * sv + bv;
-            const double dv = (double)v;
-            s1 += dv;
-            s2 += dv * dv;
+            if constexpr (STATS) {
+              const double dv = (double)v;
+              s1 += dv;
+              s2 += dv * dv;
+            }
             if (add_in) v += add_in[(size_t)m * p.ldadd + col];
             if (relu) v = fmaxf(v, 0.f);
             y_out[(size_t)m * p.ldy + col] = v;
@@ -274,7 +317,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
     st1[j] = s1;
     st2[j] = s2;
   }
-  if (!split && p.stats) {
+  if (STATS && !split && p.stats) {
     __syncthreads();  // every wave is done with its transposition slab
 #pragma unroll
     for (int j = 0; j < NREP; ++j) {
@@ -518,23 +561,24 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
       *reinterpret_cast<bf16x4*>(&plane0[c * plane_elems + sp_off(row, kq >> 1) + (kq & 1) * 4]) = pc;
     }
   };
-  auto stage_store = [&](float* A_, float* B_) {
+  auto stage_store_from = [&](float* A_, float* B_, const f32x4 (&qa)[A_PER], const f32x4 (&qb)[B_PER]) {
     if constexpr (SP) {
       __bf16* Ap = reinterpret_cast<__bf16*>(smem);
       __bf16* Bp = Ap + SP * BM * BK;
 #pragma unroll
-      for (int i = 0; i < A_PER; ++i) sp_split_store(Ap, BM * BK, lrow + RSTEP * i, ra[i]);
+      for (int i = 0; i < A_PER; ++i) sp_split_store(Ap, BM * BK, lrow + RSTEP * i, qa[i]);
 #pragma unroll
-      for (int i = 0; i < B_PER; ++i) sp_split_store(Bp, BN * BK, lrow + RSTEP * i, rb[i]);
+      for (int i = 0; i < B_PER; ++i) sp_split_store(Bp, BN * BK, lrow + RSTEP * i, qb[i]);
     } else {
 #pragma unroll
       for (int i = 0; i < A_PER; ++i)
-        *reinterpret_cast<f32x4*>(&A_[(lrow + RSTEP * i) * LDK + kq * 4]) = ra[i];
+        *reinterpret_cast<f32x4*>(&A_[(lrow + RSTEP * i) * LDK + kq * 4]) = qa[i];
 #pragma unroll
       for (int i = 0; i < B_PER; ++i)
-        *reinterpret_cast<f32x4*>(&B_[(lrow + RSTEP * i) * LDK + kq * 4]) = rb[i];
+        *reinterpret_cast<f32x4*>(&B_[(lrow + RSTEP * i) * LDK + kq * 4]) = qb[i];
     }
   };
+  auto stage_store = [&](float* A_, float* B_) { stage_store_from(A_, B_, ra, rb); };
   // do_pf: issue the next tile's global loads after the first MFMA group, so their address VALU and
   // issue slots hide in the shadow of this wave's own MFMAs instead of preceding them
   auto compute = [&](const float* A_, const float* B_, auto&& issue_next) {
@@ -672,7 +716,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
         for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
   }
 
-  conv_epilogue<BM, BN>(p, acc, smem, split, ks, m0, n0, tile_m, reinterpret_cast<double*>(smem + SMEM_BASE), p.y, p.add);
+  conv_epilogue<BM, BN, !TR, TR>(p, acc, smem, split, ks, m0, n0, tile_m, reinterpret_cast<double*>(smem + SMEM_BASE), p.y, p.add);
 }
 
 // Split-K epilogue: y = sum_ks part[ks] (+bias) (+add); optional fp64 channel statistics.
@@ -1083,8 +1127,20 @@ __device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, float*
 #endif
 }
 
-template <int MODE, int KS, int NSTAGE, int OCC, bool TL2>
+// SP = 3 (SEMSEG_ARITH_BF16X3, round 4): the same ring, the same DMA stream, but the fragments are formed for the bf16
+// matrix-core instruction.  LDS-DMA cannot transform what it moves, so the stage stays fp32 and K-major, and the split
+// happens at FRAGMENT time: a lane reads the 8 pixels of its k-group for its two rows (8 ds_read_b64, the even / odd row
+// relabelling of the fp32 kernel), cuts the 16 floats into three bf16 pieces each in registers and packs them along K —
+// which is exactly the transposition v_mfma_f32_32x32x16_bf16 needs for a K-major operand.  Each tile element is split by
+// the two waves that use it (2x the conversion VALU of the register-staged SP kernel, ~350 VALU cycles against 768
+// matrix-pipe cycles per stage and wave), in exchange for: no staging VGPRs, no ds_write pass, ONE barrier per K-step and a
+// prefetch depth set by the ring instead of one K-step (the register-staged SP kernel ran at 160 TFLOP/s fp32-equivalent,
+// latency-bound on its one-step prefetch).  KS must be 16 (one MFMA K-group per stage).
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+template <int MODE, int KS, int NSTAGE, int OCC, bool TL2, int SP = 0>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArgs pin) {
+  static_assert(SP == 0 || (SP == 3 && KS == 16), "split form: three pieces, one 16-pixel K-group per stage");
   WgradArgs p = pin;
   if (p.batch > 1) {
     const long long bz = blockIdx.y;
@@ -1245,20 +1301,112 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
     }
   };
 
+  // SP: raw fp32 fragments of a stage (8 pixels x 2 rows per operand and lane), their split into bf16 pieces, the 24 MFMAs
+  auto sp_read = [&](int slot, f32x2 (&ya)[8], f32x2 (&xa)[8]) {
+    const float* Ya = smem + slot * STAGE_F + (lhi * 8) * TM + wm * 64 + 2 * l31;
+    const float* Xa = smem + slot * STAGE_F + KS * TM + (lhi * 8) * TN + wn * 64 + 2 * l31;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      ya[kk] = *reinterpret_cast<const f32x2*>(Ya + kk * TM);
+      xa[kk] = *reinterpret_cast<const f32x2*>(Xa + kk * TN);
+    }
+  };
+  auto sp_split = [&](const f32x2 (&ya)[8], const f32x2 (&xa)[8], bf16x8 (&fa2)[2][3], bf16x8 (&fb2)[2][3]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x8 va, vb;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        va[kk] = ya[kk][i];
+        vb[kk] = xa[kk][i];
+      }
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const bf16x8 ha = __builtin_convertvector(va, bf16x8);
+        const bf16x8 hb = __builtin_convertvector(vb, bf16x8);
+        fa2[i][pc] = ha;
+        fb2[i][pc] = hb;
+        if (pc < 2) {
+          va -= __builtin_convertvector(ha, f32x8);
+          vb -= __builtin_convertvector(hb, f32x8);
+        }
+      }
+    }
+  };
+  auto sp_mfma = [&](const bf16x8 (&fa2)[2][3], const bf16x8 (&fb2)[2][3]) {
+    // small terms first, the leading product last; consecutive MFMAs go to different accumulators
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i][PA[q]], fb2[j][PB[q]], acc[i][j], 0, 0, 0);
+  };
+  auto compute_sp = [&](int slot) {
+    f32x2 ya[8], xa[8];
+    bf16x8 fa2[2][3], fb2[2][3];
+    sp_read(slot, ya, xa);
+    sp_split(ya, xa, fa2, fb2);
+    sp_mfma(fa2, fb2);
+  };
+
   const int nsteps = (kend - kbeg + KS - 1) / KS;
   // Stages past the end of this split are issued too (their rows are either another split's valid memory or out
   // of range): the DMA count per iteration stays constant, which is what the counted vmcnt relies on.
 #pragma unroll
   for (int st = 0; st < NSTAGE - 1; ++st) issue(kbeg + st * KS, st);
   int slot = 0, pslot = NSTAGE - 1;
+  if constexpr (SP != 0 && SP_PIPE != 0 && NSTAGE >= 4) {
+    // Software-pipelined form: the raw fragments of stage t + 1 are read and split WHILE the 24 matrix-core instructions
+    // of stage t issue (an in-order wave hides ~5 single-issue instructions behind each 32-cycle MFMA, and the split is
+    // ~180 VALU instructions per stage), instead of read -> wait -> split -> MFMAs in sequence.  For that, stage t + 1
+    // must have landed when iteration t starts: the counted wait moves one stage earlier (NSTAGE - 3 stages stay in
+    // flight across the barrier instead of NSTAGE - 2).  The barrier of iteration t says that every wave has finished
+    // reading stage t (it did so in iteration t - 1), so the DMA of stage t + NSTAGE - 1 may overwrite slot (t - 1).
+    bf16x8 fca[2][3], fcb[2][3];
+    {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI * (NSTAGE - 2)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      f32x2 ya[8], xa[8];
+      sp_read(0, ya, xa);
+      sp_split(ya, xa, fca, fcb);
+    }
+    int nslot_ = 1, pslot_ = NSTAGE - 1;
+    for (int t = 0; t < nsteps; ++t) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI * (NSTAGE - 3)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(kbeg + (t + NSTAGE - 1) * KS, pslot_);
+      f32x2 ya[8], xa[8];
+      bf16x8 fna[2][3], fnb[2][3];
+      sp_read(nslot_, ya, xa);        // stage t + 1 (past the end of the split: rows of another split or zeros, never used)
+      sp_mfma(fca, fcb);
+      sp_split(ya, xa, fna, fnb);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          fca[i][pc] = fna[i][pc];
+          fcb[i][pc] = fnb[i][pc];
+        }
+      pslot_ = pslot_ + 1 == NSTAGE ? 0 : pslot_ + 1;
+      nslot_ = nslot_ + 1 == NSTAGE ? 0 : nslot_ + 1;
+    }
+  } else
   for (int t = 0; t < nsteps; ++t) {
     // stage t has landed for this wave once at most NSTAGE-2 younger stages are still outstanding ...
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI * (NSTAGE - 2)) : "memory");
     // ... and for every wave after the barrier, which also says: everybody is done reading slot (t-1) % NSTAGE
     __builtin_amdgcn_s_barrier();
-    first_frags(slot);
-    issue(kbeg + (t + NSTAGE - 1) * KS, pslot);
-    compute(slot);
+    if constexpr (SP) {
+      issue(kbeg + (t + NSTAGE - 1) * KS, pslot);
+      compute_sp(slot);
+    } else {
+      first_frags(slot);
+      issue(kbeg + (t + NSTAGE - 1) * KS, pslot);
+      compute(slot);
+    }
     pslot = slot;
     slot = slot + 1 == NSTAGE ? 0 : slot + 1;
     if constexpr (TWO_LEVEL) {
@@ -1704,6 +1852,10 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
 #ifndef WGRAD_DMA_POLICY
 #define WGRAD_DMA_POLICY "6"
 #endif
+#ifndef WGRAD_SP_POLICY
+#define WGRAD_SP_POLICY 8
+#endif
+
   const char* dma_s = getenv("SEMSEG_WGRAD_DMA");
   if (!dma_s) dma_s = WGRAD_DMA_POLICY;
   int dma_env = atoi(dma_s);
@@ -1714,9 +1866,14 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
     if (tiles > thr) dma_env = vb;
   }
   const bool dma_ok = (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
-  const bool sp = big && arith == SEMSEG_ARITH_BF16X3;   // register-staged 128 x 128 kernel, split-bf16 products
-  const int dma = (big && !sp && dma_ok && dma_env >= 0 && dma_env <= 7) ? dma_env : 0;
-  static const int occ_of[8] = {3, 2, 3, 2, 5, 5, 2, 2};
+  const bool sp = big && arith == SEMSEG_ARITH_BF16X3;   // 128 x 128 tiles with split-bf16 products
+  // bf16x3 variants: 8 / 9 = the direct-to-LDS ring with the split at fragment time (4 stages, 2 workgroups per CU / 3
+  // stages, 3 per CU); 0 = the register-staged SP kernel of round 3.  SEMSEG_WGRAD_SP = 0 | 8 | 9 (A/B, tests).
+  const char* sp_s = getenv("SEMSEG_WGRAD_SP");
+  const int sp_env = sp_s ? atoi(sp_s) : WGRAD_SP_POLICY;
+  const int sp_dma = (sp && dma_ok && (sp_env == 8 || sp_env == 9)) ? sp_env : 0;
+  const int dma = sp ? sp_dma : ((big && dma_ok && dma_env >= 0 && dma_env <= 7) ? dma_env : 0);
+  static const int occ_of[10] = {3, 2, 3, 2, 5, 5, 2, 2, 2, 3};
   // Fill whole residency rounds (256 CUs x resident workgroups per CU): among the K splits that give at most two
   // rounds, take the one with the best fill (ties: fewer splits = fewer slabs to write and reduce).
   const int ROUND = 256 * occ_of[dma];
@@ -1755,7 +1912,15 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
     else if (mode == 2) conv_wgrad_dma_kernel<2, KS_, NST_, OCC_, TL_><<<grid, 256, 0, stream>>>(a);    \
     else conv_wgrad_dma_kernel<0, KS_, NST_, OCC_, TL_><<<grid, 256, 0, stream>>>(a);                   \
   } while (0)
-  if (sp) {
+#define LAUNCH_WGRAD_DMA_SP(NST_, OCC_)                                                                    \
+  do {                                                                                                    \
+    if (mode == 1) conv_wgrad_dma_kernel<1, 16, NST_, OCC_, false, 3><<<grid, 256, 0, stream>>>(a);       \
+    else if (mode == 2) conv_wgrad_dma_kernel<2, 16, NST_, OCC_, false, 3><<<grid, 256, 0, stream>>>(a);  \
+    else conv_wgrad_dma_kernel<0, 16, NST_, OCC_, false, 3><<<grid, 256, 0, stream>>>(a);                 \
+  } while (0)
+  if (sp && sp_dma == 8) LAUNCH_WGRAD_DMA_SP(4, 2);
+  else if (sp && sp_dma == 9) LAUNCH_WGRAD_DMA_SP(3, 3);
+  else if (sp) {
     if (mode == 1) conv_wgrad_kernel<128, 128, 1, 3><<<grid, 256, 0, stream>>>(a);
     else if (mode == 2) conv_wgrad_kernel<128, 128, 2, 3><<<grid, 256, 0, stream>>>(a);
     else conv_wgrad_kernel<128, 128, 0, 3><<<grid, 256, 0, stream>>>(a);
@@ -1767,6 +1932,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   else if (big && dma == 6) LAUNCH_WGRAD_DMA(16, 4, 2, true);    // 3 + two-level accumulation
   else if (big && dma == 7) LAUNCH_WGRAD_DMA(32, 2, 2, true);    // 1 + two-level accumulation
   else if (big) LAUNCH_WGRAD(128, 128); else LAUNCH_WGRAD(64, 64);
+#undef LAUNCH_WGRAD_DMA_SP
 #undef LAUNCH_WGRAD_DMA
 #undef LAUNCH_WGRAD
   const size_t total = (size_t)Co * Ci * RS / 4;   // one thread per 4 input channels

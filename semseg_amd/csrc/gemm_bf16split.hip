@@ -12,7 +12,8 @@
 //
 // Tile: 256 rows x 128 columns per workgroup of 8 waves (4 x 2, 64 x 64 each = 2 x 2 MFMA blocks), K staged BK at a
 // time: global -> registers (prefetched one stage ahead) -> split -> LDS [rows][BK] bf16 per piece (chunk-swizzled) ->
-// fragments.  Measured and set aside: experiments/gemm_bf16split_256sq.inc (256 x 256 tile, deeper pipeline).
+// fragments.  Measured and set aside in round 3 (git history, commit 9e79bfe: csrc/experiments/gemm_bf16split_256sq.inc): a
+// 256 x 256 tile with a deeper pipeline ran the six-product form in the same time.
 #include "common.h"
 #include "../../include/semseg_hip.h"
 
@@ -22,6 +23,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 constexpr int SB_BM = 256, SB_BN = 128, SB_THREADS = 512;
+#ifndef EPI_WIDE
+#define EPI_WIDE 1     // 0: direct dword stores from the accumulator layout (the round-3 epilogue; A/B builds only)
+#endif
 
 struct SplitArgs {
   const float* a;
@@ -54,8 +58,13 @@ __global__ __launch_bounds__(SB_THREADS) void gemm_rows_bf16split_kernel(const S
   constexpr int RPP = SB_THREADS / K4;              // rows covered by one pass of the workgroup
   constexpr int A_PER = SB_BM / RPP, B_PER = SB_BN / RPP;
   static_assert(A_PER >= 1 && B_PER >= 1, "stage shape");
-  __shared__ __attribute__((aligned(16))) __bf16 sA[NS][SB_BM * BK];
-  __shared__ __attribute__((aligned(16))) __bf16 sB[NS][SB_BN * BK];
+  // one allocation: [NS][SB_BM * BK] A pieces, then [NS][SB_BN * BK] B pieces; the epilogue reuses it as per-wave slabs
+  constexpr int SLAB_LD = 36;                                           // floats per slab row (conflict-free ds_read_b128)
+  constexpr int STAGE_BYTES = NS * (SB_BM + SB_BN) * BK * 2;
+  constexpr int SLAB_BYTES = (SB_THREADS / 64) * 32 * SLAB_LD * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES];
+  __bf16 (*sA)[SB_BM * BK] = reinterpret_cast<__bf16 (*)[SB_BM * BK]>(smem_raw);
+  __bf16 (*sB)[SB_BN * BK] = reinterpret_cast<__bf16 (*)[SB_BN * BK]>(smem_raw + NS * SB_BM * BK * 2);
 
   int t = xcd_remap(blockIdx.x, p.total);
   const int tn = t % p.tiles_n; t /= p.tiles_n;     // column tiles of one row panel are XCD neighbours
@@ -145,7 +154,33 @@ __global__ __launch_bounds__(SB_THREADS) void gemm_rows_bf16split_kernel(const S
     __syncthreads();
   }
 
-  // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Stored directly
+  // that is 16 dword stores per lane and block (64 per lane and tile): store-issue bound, as long as the whole K loop of a
+  // K = 256 tile (the 46 layer3 GEMMs of a PSPNet-101 step).  Each wave therefore transposes block by block through a
+  // private 32 x 36-float slab of the (now idle) staging LDS and stores 16-byte lanes: 4 stores per lane and block.
+  // Same-wave LDS traffic is ordered, so no barrier is needed between a block's writes, its reads and the next block.
+  const bool wide = EPI_WIDE && (p.ldc & 3) == 0 && (p.Nout & 3) == 0 && ((((size_t)C) & 15) == 0);
+  if (wide) {
+    float* slab = reinterpret_cast<float*>(smem_raw) + wave * (32 * SLAB_LD);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * lhi) * SLAB_LD + l31] = acc[i][j][e];
+        const int colb = n0 + wn * 64 + j * 32 + c4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = rr + 8 * t;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&slab[r * SLAB_LD + c4]);
+          const int row = m0 + wm * 64 + i * 32 + r;
+          if (row < p.M && colb < p.Nout) *reinterpret_cast<f32x4*>(&C[(size_t)row * p.ldc + colb]) = v;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -782,7 +782,13 @@ class Engine:
         return (self.sync_bn or self.force_sync_bn) and self.dist_on
 
     def _all_reduce(self, t):
-        dist.all_reduce(t)
+        """One SyncBN exchange: RCCL by default; with SEMSEG_SYNCBN_XCHG=1 the peer-memory exchange kernel
+        (semseg_amd/syncbn_xchg.py: one launch, no c10d call; opt-in until it has run across xGMI)."""
+        from . import syncbn_xchg
+        if syncbn_xchg.enabled():
+            syncbn_xchg.get(self.device).all_reduce(t)
+        else:
+            dist.all_reduce(t)
         self.syncbn_collectives_per_step += 1
 
     def _group(self, bls):
@@ -826,6 +832,9 @@ class Engine:
                     raise ValueError("Expected more than 1 value per channel when training, got input "
                                      "size [%d values per channel]" % cnt)
                 track = bm.track_running_stats and bm.running_mean is not None
+                # (folding this step into the apply kernel — every thread deriving scale / shift of its 4 channels from the
+                # [nslot][2C] sums — was built and measured in round 4: the ~1 M threads of an apply launch re-read 512 B of
+                # sums each, 42 us instead of 5 us per launch at per-GPU batch 2, +8 ms per step at batch 16)
                 ops.bn_finalize(st, cnt, bm.weight.detach(), bm.bias.detach(),
                                 bm.running_mean if track else None, bm.running_var if track else None,
                                 bm.num_batches_tracked if track else None, bl.momentum, bl.eps, bl.mean,

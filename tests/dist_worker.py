@@ -45,6 +45,9 @@ def run(world, rank, steps=2, bucket_mb=8):
         if it == 0:
             w_first = tr.flat_w.cpu().numpy()
     torch.cuda.synchronize()
+    from semseg_amd import syncbn_xchg
+    if world > 1 and syncbn_xchg.enabled():
+        syncbn_xchg.get(dev).check()          # raises if an exchange gave up waiting for a peer
     sd = m.state_dict()
     ncoll = max(e.syncbn_collectives_per_step for e in tr.engines.values())
     return np.array(losses), tr.flat_w.cpu().numpy(), sd["layer0.1.running_var"].cpu().numpy(), \

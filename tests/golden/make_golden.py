@@ -103,6 +103,7 @@ def main():
             "logits_sum": np.float64(ref_logits.double().sum().item()),
             "main_loss": np.float64(ml.item()), "aux_loss": np.float64(al.item()),
             "pred_sample": pred[:, ::5, ::5].numpy(),
+            "pred_full": pred.numpy().astype(np.uint8),
         }
         for k, gref in grads.items():
             fx["gnorm/" + k] = np.float64(gref.double().norm().item())

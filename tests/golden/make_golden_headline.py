@@ -47,15 +47,27 @@ def train_fixture(rp, segnet):
     x, y = headline_inputs(batch, size, classes)
     m.train()
     t0 = time.time()
+    grab = {}
+    hook = m.cls.register_forward_hook(lambda mod, inp, out: grab.__setitem__("scores", out.detach()))
     pred, ml, al = m(x, y)
+    hook.remove()
     (ml + 0.4 * al).backward()
     print("reference PSPNet-101 473^2 batch 16 train step on the CPU: %.1f s, main %.6f aux %.6f"
           % (time.time() - t0, ml.item(), al.item()), flush=True)
     grads = {k: p.grad.clone() for k, p in m.named_parameters()}
     new_sd = {k: v.clone() for k, v in m.state_dict().items()}
+    # top-2 margin of the reference's own upsampled train-mode scores at the sampled pixels, relative to max |score|: an
+    # argmax may legitimately differ between two fp32 implementations only where this margin is inside the logits tolerance
+    import torch.nn.functional as F
+    up = F.interpolate(grab["scores"], size=(size, size), mode="bilinear", align_corners=True)
+    assert torch.equal(up.max(1)[1], pred)
+    top2 = up[:, :, ::5, ::5].topk(2, dim=1)[0]
+    margin = ((top2[:, 0] - top2[:, 1]) / up.abs().max()).numpy().astype(np.float32)
+    del up, top2
     fx = {
         "main_loss": np.float64(ml.item()), "aux_loss": np.float64(al.item()),
         "pred_sample": pred[:, ::5, ::5].numpy().astype(np.uint8),
+        "margin_sample": margin,
         "pred_hist": np.bincount(pred.reshape(-1).numpy(), minlength=classes).astype(np.int64),
     }
     names = list(grads)
@@ -86,16 +98,26 @@ def ms_fixture(rp, segnet):
     m = rp.PSPNet(layers=layers, classes=classes, zoom_factor=8, pretrained=False)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = segnet.recipe_state_dict(shapes, seed=5)
-    # as in tests/test_infer_gpu.py: the recipe's eval logits reach ~1e4, where softmax turns fp32 round-off into O(0.1)
-    # probability changes; scale the classifier so that the probabilities are well conditioned
-    sd["cls.4.weight"] *= 1e-3
-    sd["cls.4.bias"] *= 1e-3
     m.load_state_dict(sd)
     m.eval()
     g = np.random.default_rng(1)
     img = (g.random((512, 512, 3)) * 255).astype(np.float32)
     mean = [0.485 * 255, 0.456 * 255, 0.406 * 255]
     std = [0.229 * 255, 0.224 * 255, 0.225 * 255]
+    # The recipe's eval-mode logits of this 101-layer net are huge (random running statistics), and softmax turns the fp32
+    # round-off of such logits (~1e-6 relative) into O(0.01) probability changes at near-tie pixels (first version of this
+    # fixture, classifier scaled by 1e-3 as tests/test_infer_gpu.py does for PSPNet-50: the HIP path differed by 1.6e-2 in
+    # probability at 0.998 argmax agreement).  The classifier is therefore scaled so that max |logit| = 10 on the centre
+    # crop: probabilities are then well conditioned and the 2e-4 bound means what it says.  The factor travels in the file.
+    with torch.no_grad():
+        probe = torch.from_numpy(((img[19:492, 19:492] - np.array(mean, np.float32)) / np.array(std, np.float32))
+                                 .transpose(2, 0, 1))[None]
+        amax = float(m(probe).abs().max())
+    cls_scale = np.float32(10.0 / amax)
+    print("max |logit| on the centre crop %.4g -> classifier scale %.6g" % (amax, cls_scale), flush=True)
+    with torch.no_grad():
+        m.cls[4].weight.mul_(float(cls_scale))
+        m.cls[4].bias.mul_(float(cls_scale))
     calls = [0]
 
     def net(x):
@@ -107,8 +129,9 @@ def ms_fixture(rp, segnet):
           flush=True)
     assert calls[0] == 46
     np.savez_compressed(os.path.join(HERE, "pspnet101_c150_ms512.npz"),
-                        argmax=arg.astype(np.uint8), prob_sample=prob[::4, ::4, :].astype(np.float32),
-                        prob_max=prob.max(axis=2).astype(np.float32), forwards=np.int64(calls[0]))
+                        argmax=arg.astype(np.uint8), prob_sample=prob[::16, ::16, :].astype(np.float32),
+                        prob_max=prob.max(axis=2)[::2, ::2].astype(np.float32), forwards=np.int64(calls[0]),
+                        cls_scale=cls_scale)
     print("pspnet101_c150_ms512.npz written", flush=True)
 
 

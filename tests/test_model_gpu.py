@@ -124,7 +124,12 @@ def run_case(report, name, arch, layers, classes, size, batch, gold=None, psa_cf
         assert e < 1e-4, e
         assert abs(ml.item() - fx["main_loss"]) / fx["main_loss"] < 1e-5
         assert abs(al.item() - fx["aux_loss"]) / fx["aux_loss"] < 1e-5
-        assert float((pred[:, ::5, ::5].cpu().numpy() == fx["pred_sample"]).mean()) > 0.999
+        # the reference's argmax map: the same 0.999 bound as against the oracle above, on ALL pixels (rounds 1-3 compared a
+        # 450-pixel subsample, whose granularity turned 0.999 into "no pixel may differ"; DESIGN.md 2.1 ledger entry 8)
+        ndiff = int((pred.cpu().numpy() != fx["pred_full"]).sum())
+        report("   argmax vs the reference fixture: %d of %d pixels differ (%d of the 450 on the old sampling grid)"
+               % (ndiff, pred.numel(), int((pred[:, ::5, ::5].cpu().numpy() != fx["pred_sample"]).sum())))
+        assert 1.0 - ndiff / pred.numel() > 0.999
         params = dict(m.named_parameters())
         for k in ("cls.4.bias", "cls.4.weight", "aux.4.bias"):  # the well-conditioned gradients
             gk = params[k].grad.cpu().numpy()

@@ -766,11 +766,13 @@ WINO_CASES = [  # N, H, W, Ci, Co, dilation
 ]
 
 
+@pytest.mark.parametrize("arith", [0, 3])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_winograd_conv_fwd_dgrad_wgrad(case, report):
+def test_winograd_conv_fwd_dgrad_wgrad(case, arith, report):
     """Winograd F(2x2, 3x3) path (input / filter / output transforms + the batched matrix-core GEMMs) against fp64
     F.conv2d and its gradients: kernel 3, stride 1, padding = dilation; operands in wider buffers; statistics and the
-    accumulate-into-dx form included.  Same bound as the direct kernels."""
+    accumulate-into-dx form included.  Same bound as the direct kernels, in both arithmetics (0 = SEMSEG_ARITH_F32,
+    3 = SEMSEG_ARITH_BF16X3 on the batched row GEMMs and the batched K-major GEMM of the weight gradient)."""
     from semseg_amd import ops
     N, H, W, Ci, Co, d = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
@@ -790,7 +792,7 @@ def test_winograd_conv_fwd_dgrad_wgrad(case, report):
     V = torch.empty(16 * T * Ci, device=DEV)
     Mbuf = torch.empty(16 * T * max(Ci, Co), device=DEV)
     st = torch.zeros(ops.NSLOT * 2 * Co, dtype=torch.float64, device=DEV)
-    ops.wino_conv_fwd(xb[..., 16:], ldx, wc, yb, ldy, N, H, W, d, V, Mbuf, stats=st, nslot=ops.NSLOT)
+    ops.wino_conv_fwd(xb[..., 16:], ldx, wc, yb, ldy, N, H, W, d, V, Mbuf, stats=st, nslot=ops.NSLOT, arith=arith)
     y = yb[..., :Co].permute(0, 3, 1, 2)
     e_f = relerr(y, y64.detach())
     assert torch.isnan(yb[..., Co:]).all()                     # nothing written beyond the valid channels
@@ -810,7 +812,7 @@ def test_winograd_conv_fwd_dgrad_wgrad(case, report):
     base = torch.randn(N, H, W, ldx, device=DEV)
     dxb = base.clone()
     Vdy = torch.empty(16 * T * wc.Kc, device=DEV)
-    ops.wino_conv_dgrad(dyb, ldy, wc, dxb[..., 16:], ldx, N, H, W, d, Vdy, Mbuf, add=base[..., 16:], ldadd=ldx)
+    ops.wino_conv_dgrad(dyb, ldy, wc, dxb[..., 16:], ldx, N, H, W, d, Vdy, Mbuf, add=base[..., 16:], ldadd=ldx, arith=arith)
     dx = (dxb[..., 16:16 + Ci] - base[..., 16:16 + Ci]).permute(0, 3, 1, 2)
     e_d = relerr(dx, x64.grad)
     assert torch.equal(dxb[..., :16], base[..., :16]) and torch.equal(dxb[..., 16 + Ci:], base[..., 16 + Ci:])
@@ -822,7 +824,7 @@ def test_winograd_conv_fwd_dgrad_wgrad(case, report):
     sums = torch.zeros(ops.NSLOT * 2 * Ci, dtype=torch.float64, device=DEV)
     gb = torch.full((N, H, W, ldx), float("nan"), device=DEV)
     ops.wino_input_transform(dyb, ldy, Vdy, N, H, W, wc.Kc, d)
-    ops.gemm_rows_batched(Vdy, wc.Kc, T * wc.Kc, wc.U_dgrad, wc.Ci_pad * wc.Kc, Mbuf, Ci, T * Ci, T, wc.Kc, Ci, 16)
+    ops.gemm_rows_batched(Vdy, wc.Kc, T * wc.Kc, wc.U_dgrad, wc.Ci_pad * wc.Kc, Mbuf, Ci, T * Ci, T, wc.Kc, Ci, 16, arith=arith)
     ops.wino_output_transform_bnreduce(Mbuf, Ci, gb[..., 16:], ldx, N, H, W, Ci, d, act[..., 16:], ldx, ybn, Ci + 4, mean,
                                        invstd, sums, ops.NSLOT, add=base[..., 16:], ldadd=ldx)
     g_ref = (nhwc(x64.grad) + base[..., 16:16 + Ci].double().cpu()) * (act[..., 16:16 + Ci] > 0).cpu()
@@ -836,9 +838,9 @@ def test_winograd_conv_fwd_dgrad_wgrad(case, report):
     dU = torch.empty(16 * Co * Ci, device=DEV)
     scratch = torch.empty(16 * 1024 * 1024, device=DEV)
     dw = torch.full((Co, Ci, 3, 3), float("nan"), device=DEV)
-    ops.wino_conv_wgrad(V, dyb, ldy, wc, dw, N, H, W, d, Yh, dU, scratch)
+    ops.wino_conv_wgrad(V, dyb, ldy, wc, dw, N, H, W, d, Yh, dU, scratch, arith=arith)
     e_w = relerr(dw, w64.grad)
-    report("winograd %s: fwd %.2e stats %.2e dgrad %.2e wgrad %.2e" % (case, e_f, e_s, e_d, e_w))
+    report("winograd %s arith %d: fwd %.2e stats %.2e dgrad %.2e wgrad %.2e" % (case, arith, e_f, e_s, e_d, e_w))
     assert e_f < 2e-5 and e_d < 2e-5 and e_w < 2e-5 and e_s < 1e-5
 
 
@@ -937,12 +939,15 @@ def test_conv_arith_bf16x3_1x1(code, report, monkeypatch):
 
 @pytest.mark.parametrize("case", [(2, 23, 21, 256, 128, 1, 1, 0, 1), (2, 19, 17, 128, 256, 3, 1, 2, 2), (2, 21, 21, 256, 256, 1, 2, 0, 1),
                                   (1, 33, 33, 128, 128, 3, 1, 1, 1)])
-def test_conv_wgrad_arith_bf16x3(case, report, monkeypatch):
+@pytest.mark.parametrize("sp_variant", [8, 9, 0])
+def test_conv_wgrad_arith_bf16x3(case, sp_variant, report, monkeypatch):
     """SEMSEG_ARITH_BF16X3 per launch: the SP instance of the 128 x 128 weight-gradient kernel (pixel-contiguous bf16
     piece planes, six bf16 matrix-core products) in its three gather modes (1x1, "same" 3x3 with dilation, strided)
     next to the fp32 kernels on the same operands, against fp64: rms within 2x of the fp32 path's (+1e-7)."""
     from semseg_amd import ops
     monkeypatch.setenv("SEMSEG_WGRAD_SMALL", "0")          # keep the 128 x 128 path on these small grids
+    # 8 / 9: the direct-to-LDS ring with the split at fragment time (4 stages / 3 stages); 0: the register-staged SP kernel
+    monkeypatch.setenv("SEMSEG_WGRAD_SP", str(sp_variant))
     N, H, W, Ci, Co, k, s_, p_, d = case
     g = torch.Generator().manual_seed(31)
     x = torch.relu(torch.randn(N, Ci, H, W, generator=g))
@@ -959,7 +964,7 @@ def test_conv_wgrad_arith_bf16x3(case, report, monkeypatch):
                        arith=ops.ARITH_BF16X3 if split else ops.ARITH_F32)
         torch.cuda.synchronize()
         errs.append(rms(dw))
-    report("conv_wgrad split mode %s: rms %.2e (fp32 path %.2e)" % (case, errs[1], errs[0]))
+    report("conv_wgrad bf16x3 variant %d %s: rms %.2e (fp32 path %.2e)" % (sp_variant, case, errs[1], errs[0]))
     assert errs[1] <= 2 * errs[0] + 1e-7
 
 
