@@ -8,12 +8,16 @@ def short(n):
     return (m.group(2) if m else n).strip()
 def family(k):
     """Template instantiations that bench.py's KernelTimer reports as one family: the weight-gradient kernel's
-    addressing MODE and the forward/data-gradient kernel's two-level-accumulation flag are dropped."""
-    if k.startswith('conv_wgrad_dma_kernel<'): return 'conv_wgrad_dma_kernel<128x128>'
-    m = re.match(r'conv_wgrad_kernel<(\d+), (\d+), \d+(, 0)?>', k)
-    if m: return 'conv_wgrad_kernel<%s, %s>' % (m.group(1), m.group(2))
-    m = re.match(r'conv_igemm_kernel<(\d+), (\d+), (true|false), (\d+), (true|false)(, 0)?>', k)
-    if m: return 'conv_igemm_kernel<%s, %s, %s, %s>' % m.groups()[:4]
+    addressing MODE and the forward/data-gradient kernel's two-level-accumulation flag are dropped; the SP = 3
+    (SEMSEG_ARITH_BF16X3) instances keep an SP3 tag, as in the KernelTimer labels."""
+    m = re.match(r'conv_wgrad_dma_kernel<\d+, \d+, \d+, \d+, (?:true|false)(?:, (\d))?>', k)
+    if m: return 'conv_wgrad_dma_kernel<128x128%s>' % (',SP3' if m.group(1) == '3' else '')
+    m = re.match(r'conv_wgrad_kernel<(\d+), (\d+), \d+(?:, (\d))?>', k)
+    if m: return 'conv_wgrad_kernel<%s,%s%s>' % (m.group(1), m.group(2), ',SP3' if m.group(3) == '3' else '')
+    m = re.match(r'conv_igemm_kernel<(\d+), (\d+), (true|false), (\d+), (?:true|false)(?:, (\d))?>', k)
+    if m: return 'conv_igemm_kernel<%s,%s,%s,%s%s>' % (m.group(1), m.group(2), m.group(3), m.group(4), ',SP3' if m.group(5) == '3' else '')
+    m = re.match(r'gemm_rows_bf16split_kernel<(\d+), (\d+)>', k)
+    if m: return 'gemm_rows_bf16split_kernel<%s,%s>' % m.groups()
     return k
 def agg(path):
     a = collections.defaultdict(lambda: collections.defaultdict(float)); seen = collections.defaultdict(dict)
@@ -28,7 +32,7 @@ w = agg(os.path.join(g, tag + "_write", "pmc_counter_collection.csv"))
 m = agg(os.path.join(g, tag + "_mfma", "pmc_counter_collection.csv"))
 res = {}
 for k in f:
-    if not any(t in k for t in ("conv_igemm", "conv_wgrad", "bn_", "splitk", "wino_")): continue
+    if not any(t in k for t in ("conv_igemm", "conv_wgrad", "gemm_rows", "bn_", "splitk", "wino_")): continue
     n = f[k]['launches']
     fetch = f[k]['FETCH_SIZE'] * 1024 * 2 / n
     write = w.get(k, {}).get('WRITE_SIZE', 0) * 1024 / max(w.get(k, {}).get('launches', 1), 1)
@@ -36,7 +40,7 @@ for k in f:
     if mm.get('GRBM_GUI_ACTIVE'):
         util = mm.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (mm['GRBM_GUI_ACTIVE'] / 8 * 1024)
         clk = mm['GRBM_GUI_ACTIVE'] / 8 / mm['dur_ns']
-    res[k] = {"launches_per_2_steps": n, "hbm_fetch_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
+    res[k] = {"launches_in_the_pmc_run": n, "hbm_fetch_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
               "hbm_bytes_per_launch": round(fetch + write), "mfma_busy_frac": None if util is None else round(util, 4),
               "clock_ghz": None if clk is None else round(clk, 3)}
 json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE> (three separate passes) --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing",
@@ -49,7 +53,7 @@ for k, v in sorted(res.items(), key=lambda kv: -(kv[1]['mfma_busy_frac'] or 0))[
 # the copied line from THIS round's passes (everything else in the line is as bench.py printed it)
 bp = os.path.join(ROOT, "profiles", tag + "_bench_n1.json")
 d = json.load(open(bp))
-key = family(d["roofline"]["kernel"].split("+")[0].split("(")[0].replace(",", ", "))
+key = d["roofline"]["kernel"].split("+")[0].split("(")[0].replace(" ", "")
 if key in res:
     d["roofline"]["traffic"] = res[key]["hbm_bytes_per_launch"]
     d["roofline"]["mfma_busy_frac_pmc"] = res[key]["mfma_busy_frac"]

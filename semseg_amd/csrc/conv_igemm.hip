@@ -376,8 +376,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
 // SP = 3 (SEMSEG_ARITH_BF16X3, include/semseg_hip.h) cuts each fp32 operand into three
 // bf16 pieces between the global load and the LDS store and forms the product from six v_mfma_f32_32x32x16_bf16 per
 // 16 K instead of eight v_mfma_f32_32x32x2_f32 — same gather, same accumulators, same epilogues.
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 template <int BM, int BN, bool TR, int RS_T, bool TL, int SP = 0>
 __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const ConvArgs pin) {
@@ -398,7 +396,10 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
   constexpr int EPI = (NT / 64) * 64 * LDK;  // per-wave transposition slabs of the epilogue
   constexpr int SMEM_BASE = STAGE > EPI ? STAGE : EPI;
   constexpr int RED2_F = TR ? 2 * (BM / 64) * BN * 2 * 2 : 0;   // fp64 column sums of the fused BatchNorm-backward reduction
-  constexpr int SMEM_F = SMEM_BASE + RED2_F;
+  // they live behind the epilogue's transposition slabs — inside the staging area when that is larger than the slabs (the
+  // bf16x3 128 x 128 instances: 48 KB instead of 56 KB, i.e. three workgroups per CU instead of two), else behind it
+  constexpr int RED2_OFF = (EPI + RED2_F <= SMEM_BASE) ? EPI : SMEM_BASE;
+  constexpr int SMEM_F = (RED2_OFF + RED2_F > SMEM_BASE) ? RED2_OFF + RED2_F : SMEM_BASE;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
   float* As = smem;
   float* Bs = smem + BM * LDK;
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
 #pragma unroll
     for (int c = 0; c < (SP ? SP : 1); ++c) {
       const bf16x4 pc = __builtin_convertvector(r, bf16x4);
-      if (c + 1 < SP) r -= __builtin_convertvector(pc, f32x4);
+      if (c + 1 < SP) r -= bf16x4_to_f32(pc);
       *reinterpret_cast<bf16x4*>(&plane0[c * plane_elems + sp_off(row, kq >> 1) + (kq & 1) * 4]) = pc;
     }
   };
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
         for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
   }
 
-  conv_epilogue<BM, BN, !TR, TR>(p, acc, smem, split, ks, m0, n0, tile_m, reinterpret_cast<double*>(smem + SMEM_BASE), p.y, p.add);
+  conv_epilogue<BM, BN, !TR, TR>(p, acc, smem, split, ks, m0, n0, tile_m, reinterpret_cast<double*>(smem + RED2_OFF), p.y, p.add);
 }
 
 // Split-K epilogue: y = sum_ks part[ks] (+bias) (+add); optional fp64 channel statistics.
@@ -1023,7 +1024,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
 #pragma unroll
         for (int pc = 0; pc < SP; ++pc) {
           const bf16x4 h = __builtin_convertvector(v, bf16x4);
-          if (pc + 1 < SP) v -= __builtin_convertvector(h, f32x4);
+          if (pc + 1 < SP) v -= bf16x4_to_f32(h);
           *reinterpret_cast<bf16x4*>(&plane0[pc * plane_elems + sp_off(quad * 4 + c, pg >> 1) + (pg & 1) * 4]) = h;
         }
       }
@@ -1136,7 +1137,6 @@ __device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, float*
 // matrix-pipe cycles per stage and wave), in exchange for: no staging VGPRs, no ds_write pass, ONE barrier per K-step and a
 // prefetch depth set by the ring instead of one K-step (the register-staged SP kernel ran at 160 TFLOP/s fp32-equivalent,
 // latency-bound on its one-step prefetch).  KS must be 16 (one MFMA K-group per stage).
-typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE, int KS, int NSTAGE, int OCC, bool TL2, int SP = 0>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArgs pin) {
@@ -1327,8 +1327,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
         fa2[i][pc] = ha;
         fb2[i][pc] = hb;
         if (pc < 2) {
-          va -= __builtin_convertvector(ha, f32x8);
-          vb -= __builtin_convertvector(hb, f32x8);
+          va -= bf16x8_to_f32(ha);
+          vb -= bf16x8_to_f32(hb);
         }
       }
     }

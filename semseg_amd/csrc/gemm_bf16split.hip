@@ -19,8 +19,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 constexpr int SB_BM = 256, SB_BN = 128, SB_THREADS = 512;
 #ifndef EPI_WIDE
@@ -42,7 +40,7 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[NS]) {
 #pragma unroll
   for (int c = 0; c < NS; ++c) {
     out[c] = __builtin_convertvector(r, bf16x4);
-    if (c + 1 < NS) r -= __builtin_convertvector(out[c], f32x4);
+    if (c + 1 < NS) r -= bf16x4_to_f32(out[c]);
   }
 }
 

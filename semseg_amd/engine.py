@@ -570,7 +570,7 @@ class Engine:
     def _wgrad_family(big, arith):
         if not big:
             return "conv_wgrad_kernel<64,64>+reduce"
-        return "conv_wgrad_kernel<128,128,SP3>+reduce" if arith == ops.ARITH_BF16X3 else "conv_wgrad_dma_kernel<128x128>+reduce"
+        return "conv_wgrad_dma_kernel<128x128%s>+reduce" % _fam(arith)
 
     def _conv_bwd(self, x, y, cl, m):
         dy = y.grad

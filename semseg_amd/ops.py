@@ -118,7 +118,7 @@ def _load_tables():
 TILE_CODES = (128, 64, 1128, 1064)   # 128x128, 128x64, 64x128, 64x64 (rows x columns; include/semseg_hip.h)
 TILE_TIMES = {}   # key -> {tile code: ms per launch}, filled in tuning mode only
 # tile shapes measured with the SEMSEG_ARITH_BF16X3 instances of the kernels: keys suffixed "|sp"
-TILE_TABLE_SP_PATH = TILE_TABLE_PATH.replace("tile_table.json", "tile_table_sp.json")
+TILE_TABLE_SP_PATH = _os.environ.get("SEMSEG_TILE_TABLE_SP") or TILE_TABLE_PATH.replace("tile_table.json", "tile_table_sp.json")
 TILE_CHOICE = _load_tables()
 
 

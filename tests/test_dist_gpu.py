@@ -164,8 +164,9 @@ def test_syncbn_peer_memory_exchange(report):
     """The opt-in SyncBN exchange through IPC-mapped fine-grained memory (csrc/xchg.hip, SEMSEG_SYNCBN_XCHG=1)
     with 2 and 4 processes on the test box's ONE GPU: (1) the raw exchange == rank-ordered fp64 sum of the ranks' vectors, bit
     for bit, on every rank, for the vector sizes / slot counts the engine uses, plus 200 back-to-back exchanges with no host
-    synchronisation; (2) a 2-rank training run with the exchange in place of the c10d all-reduce: every loss, weight and
-    running statistic bit-identical to the c10d run (a + b is the same in either order).  If the kernels of two processes
+    synchronisation; (2) a 2-rank training run with the exchange in place of the c10d all-reduce: first-step losses bit-identical
+    to the c10d run (a + b is the same in either order), replicas bit-identical, later quantities within the run-to-run noise
+    of the two backward kernels that merge with fp32 atomics (bounds of test_eight_ranks_equal_single_process).  If the kernels of two processes
     cannot be co-resident on this box the exchange gives up after ~1 s (bounded spins) and the test is skipped with that
     reason — the path is opt-in either way."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -189,9 +190,22 @@ def test_syncbn_peer_memory_exchange(report):
                                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, tmp],
                               env=dict(env, SEMSEG_SYNCBN_XCHG=mode), timeout=900)
         res[mode] = [np.load(os.path.join(tmp, "rank%d_of2.npz" % k)) for k in range(2)]
+    x0, x1 = res["1"]
+    # the replicas of the exchange run stay bit-identical (every rank sums the slots in rank order)
+    assert np.array_equal(x0["w"], x1["w"]) and np.array_equal(x0["rv"], x1["rv"]) and np.array_equal(x0["rm"], x1["rm"])
+    assert int(x0["ncoll"]) == int(res["0"][0]["ncoll"])
+    e = {}
     for k in range(2):
-        for key in ("losses", "w", "rv", "rm", "w1"):
-            assert np.array_equal(res["0"][k][key], res["1"][k][key]), (k, key)
-    assert int(res["1"][0]["ncoll"]) == int(res["0"][0]["ncoll"])
+        c, x = res["0"][k], res["1"][k]
+        # the first step's losses depend on the forward only (initial weights + SyncBN statistics): a + b is the same sum in
+        # either order, so they are bit-identical to the c10d run; everything after the first update also carries the fp32
+        # atomics of two backward kernels (bilinear_bwd of the PPM branches, stem_wgrad), which differ run to run
+        assert np.array_equal(c["losses"][0], x["losses"][0]), (k, c["losses"][0], x["losses"][0])
+        e[k] = (np.abs(c["w1"] - x["w1"]).max() / np.abs(c["w1"]).max(), np.abs(c["w"] - x["w"]).max() / np.abs(c["w"]).max(),
+                np.abs(c["losses"][1] - x["losses"][1]).max() / np.abs(c["losses"][1]).max(),
+                np.abs(c["rv"] - x["rv"]).max() / np.abs(c["rv"]).max())
+        assert e[k][0] < 2e-4 and e[k][1] < 2e-2 and e[k][2] < 5e-3 and e[k][3] < 1e-4, e[k]
     report("2-rank training, SyncBN statistics through the peer-memory exchange instead of c10d (%d exchanges per step): "
-           "losses, weights and running statistics bit-identical" % int(res["1"][0]["ncoll"]))
+           "first-step losses bit-identical, replicas bit-identical; vs the c10d run weights after 1 / 2 steps %.1e / %.1e, "
+           "second-step losses %.1e, running_var %.1e (run-to-run fp32-atomics noise)"
+           % (int(x0["ncoll"]), e[0][0], e[0][1], e[0][2], e[0][3]))
