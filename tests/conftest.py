@@ -25,3 +25,13 @@ def report():
         print(msg)
     yield log
     f.close()
+
+
+@pytest.fixture(params=["bf16x3", "f32"])
+def arith(request):
+    """Both arithmetics of the conv GEMMs (include/semseg_hip.h): the engine default (SEMSEG_ARITH_BF16X3) and the forced exact
+    path (SEMSEG_ARITH_F32).  Tests that take this fixture run twice; engines built inside the test pick the value up."""
+    from semseg_amd import engine
+    old = engine.set_arith(request.param)
+    yield request.param
+    engine.set_arith(old)

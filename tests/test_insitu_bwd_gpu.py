@@ -43,9 +43,9 @@ def _case(report, name, arch, layers, classes, size, batch, psa_cfg=None, oracle
     return chk
 
 
-def test_insitu_pspnet50_small(report):
-    """Fast variant (every op kind of the PSPNet path, 73x73)."""
-    chk = _case(report, "pspnet50 c21 73^2 b2", "psp", 50, 21, 73, 2)
+def test_insitu_pspnet50_small(arith, report):
+    """Fast variant (every op kind of the PSPNet path, 73x73), in both arithmetics."""
+    chk = _case(report, "pspnet50 c21 73^2 b2 [%s]" % arith, "psp", 50, 21, 73, 2)
     kinds = {r[0] for r in chk.rows}
     assert {"conv", "bn_act", "stem", "maxpool", "upsample", "ppm_pool", "ce"} <= kinds
 
@@ -66,9 +66,10 @@ def test_insitu_psanet_variants(cfg, report):
 
 
 @pytest.mark.skipif(os.environ.get("SEMSEG_SKIP_BIG_INSITU") == "1", reason="big in-situ cases disabled")
-def test_insitu_pspnet101_473(report):
-    """The metric model at the metric resolution (per-GPU batch 2)."""
-    chk = _case(report, "pspnet101 c150 473^2 b2", "psp", 101, 150, 473, 2)
+def test_insitu_pspnet101_473(arith, report):
+    """The metric model at the metric resolution (per-GPU batch 2): the engine default (bf16x3 products) and the forced exact-fp32
+    path, same criteria."""
+    chk = _case(report, "pspnet101 c150 473^2 b2 [%s]" % arith, "psp", 101, 150, 473, 2)
     assert sum(1 for r in chk.rows if r[0] == "conv" and r[2].startswith("wgrad")) == 113   # every MFMA conv of the net
     # the 23 + 3 dilated conv2 of layer3 / layer4, the 3 stride-1 conv2 of layer2 and both head convs run the Winograd path
     assert sum(1 for r in chk.rows if r[2] == "wgrad-wino") == 31

@@ -140,8 +140,8 @@ def run_case(report, name, arch, layers, classes, size, batch, gold=None, psa_cf
         report("%s: matches golden fixture %s (reference outputs)" % (name, gold))
 
 
-def test_pspnet50_small_vs_oracle_and_golden(report):
-    run_case(report, "pspnet50 c21 73^2 b2", "psp", 50, 21, 73, 2, gold="pspnet50_c21_s73_b2.npz")
+def test_pspnet50_small_vs_oracle_and_golden(arith, report):
+    run_case(report, "pspnet50 c21 73^2 b2 [%s]" % arith, "psp", 50, 21, 73, 2, gold="pspnet50_c21_s73_b2.npz")
 
 
 def test_pspnet50_ade_shape(report):
@@ -149,7 +149,7 @@ def test_pspnet50_ade_shape(report):
     run_case(report, "pspnet50 c150 473^2 b2", "psp", 50, 150, 473, 2)
 
 
-def test_pspnet101_logits(report):
+def test_pspnet101_logits(arith, report):
     """Metric model: PSPNet101 473^2 eval logits vs oracle."""
     from oracle import segnet
     m, sd = build("psp", 101, 150)
@@ -159,7 +159,7 @@ def test_pspnet101_logits(report):
     m = m.cuda().eval()
     out = m(x.cuda())
     e = rel(out, ref)
-    report("pspnet101 c150 473^2 b1 eval logits %.2e (|ref|max %.3e)" % (e, float(ref.abs().max())))
+    report("pspnet101 c150 473^2 b1 eval logits [%s] %.2e (|ref|max %.3e)" % (arith, e, float(ref.abs().max())))
     assert e < 1e-4
 
 
@@ -186,9 +186,9 @@ PSA_CFG = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=9, mask_w=9, n
                psa_softmax=True)
 
 
-def test_psanet50_small_vs_oracle_and_golden(report):
+def test_psanet50_small_vs_oracle_and_golden(arith, report):
     """configs[3] path at CPU-affordable size: PSANet (psa_type 2, collect + distribute, shrink 2)."""
-    run_case(report, "psanet50 c19 65^2 b2", "psa", 50, 19, 65, 2, gold="psanet50_c19_s65_b2.npz", psa_cfg=PSA_CFG)
+    run_case(report, "psanet50 c19 65^2 b2 [%s]" % arith, "psa", 50, 19, 65, 2, gold="psanet50_c19_s65_b2.npz", psa_cfg=PSA_CFG)
 
 
 @pytest.mark.parametrize("cfg", [
