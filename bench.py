@@ -253,16 +253,11 @@ def trainer_leg(args, dev, world, rank, B, steps, warmup, arith, kernel_timing, 
         g = torch.Generator().manual_seed(1000 + rank)
         x = torch.randn(B, 3, args.size, args.size, generator=g).to(dev)
         y = torch.randint(0, args.classes, (B, args.size, args.size), generator=g).to(dev)
-        max_iter = steps + warmup + 1 + ISO_STEPS
+        max_iter = steps + warmup + 1 + 2 * ISO_STEPS
         it = 0
         for _ in range(warmup):
             tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
             it += 1
-        kt = None
-        if rank == 0 and kernel_timing:
-            kt = E.KernelTimer()
-            for e in tr.engines.values():
-                e.ktimer = kt
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
@@ -286,10 +281,20 @@ def trainer_leg(args, dev, world, rank, B, steps, warmup, arith, kernel_timing, 
             out["n_sync"] = getattr(e, "syncbn_collectives_per_step", None)
             out["two_stream_backward"] = bool(e.side_wgrad)
             out["convs_bf16x3"] = sum(1 for c in e.convs.values() if c is not None and c.arith == 3)
-        # Serialized leg (every rank runs it: the steps contain the SyncBN / gradient collectives): ISO_STEPS more steps
-        # with all kernels on one stream, HIP-event timed on rank 0 -> per-kernel rates that are not inflated by the
-        # side-stream concurrency of the timed region.
+        # The timed region above carries NO instrumentation (rounds 1-3 recorded two HIP events around every matrix-core
+        # launch inside it: ~1 ms per step at batch 16, ~3 ms at per-GPU batch 2).  Kernel timing runs on extra steps:
+        # (1) ISO_STEPS steps in the configuration of the timed region (two streams) -> kernel_families_in_step;
+        # (2) the serialized leg (every rank runs both: the steps contain the SyncBN / gradient collectives): ISO_STEPS more
+        # steps with all kernels on one stream, HIP-event timed on rank 0 -> per-kernel rates that are not inflated by
+        # the side-stream concurrency.
         if kernel_timing:
+            kt = E.KernelTimer() if rank == 0 else None
+            for e in tr.engines.values():
+                e.ktimer = kt
+            for _ in range(ISO_STEPS):
+                tr.step(x, y, poly_learning_rate(0.01, it, max_iter))
+                it += 1
+            torch.cuda.synchronize()
             kt_iso = E.KernelTimer() if rank == 0 else None
             saved = [(e, e.side_wgrad, e.hipri_main) for e in tr.engines.values()]
             for e, _, _ in saved:
@@ -462,7 +467,9 @@ def main():
                                                                                      PEAK_BF16X3_TFLOPS,
                                                                                      PEAK_F32_MFMA_TFLOPS))
             roof["measured"] = ("HIP events on the launch stream over %d steps run right after the timed region with "
-                                "every kernel on ONE stream (in_step: the same family inside the timed region)" % ISO_STEPS)
+                                "every kernel on ONE stream (in_step: the same family over %d more steps in the two-stream "
+                                "configuration of the timed region; the timed region itself carries no events)"
+                                % (ISO_STEPS, ISO_STEPS))
             _attach_pmc(roof, world)
             out["roofline"] = roof
             out["kernel_families"] = leg["kernel_families"]

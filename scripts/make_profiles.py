@@ -60,7 +60,7 @@ if key in res:
     d["roofline"]["traffic_note"] = "traffic / mfma_busy_frac_pmc re-read from profiles/%s_pmc_per_kernel.json after the PMC passes of the same build" % tag
     json.dump(d, open(bp, "w"))
 d = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_n1.json")))
-print(d['value'], d['ms_per_step'], d['whole_step_frac_of_f32_mfma_peak']); print(d['roofline'])
+print(d['value'], d['ms_per_step'], d.get('whole_step_frac_of_f32_mfma_peak')); print(d['roofline'])
 for k, v in d['kernel_families'].items(): print(' ', k, v)
 rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv"))))
 for r in rows[:6]: print(short(r['Name']), r['Calls'], "avg us %.1f" % (float(r['AverageNs']) / 1e3))
@@ -85,7 +85,7 @@ if os.path.exists(sp):
         fo.write("family,calls,total_ms,avg_us\n")
         for k, (c, t) in sorted(fs.items(), key=lambda kv: -kv[1][1]):
             fo.write('"%s",%d,%.3f,%.2f\n' % (k, c, t / 1e6, t / c / 1e3))
-    w2 = fs.get('conv_wgrad_dma_kernel<128x128>'); r2 = fs.get('wgrad_reduce_unpack_kernel')
+    w2 = fs.get('conv_wgrad_dma_kernel<128x128,SP3>') or fs.get('conv_wgrad_dma_kernel<128x128>'); r2 = fs.get('wgrad_reduce_unpack_kernel')
     if w2: print("serialized rocprof: 128x128 weight-gradient kernel avg %.1f us over %d launches (+ reduce %.1f us)" % (w2[1] / w2[0] / 1e3, w2[0], r2[1] / r2[0] / 1e3 if r2 else 0))
-wg = fam.get('conv_wgrad_dma_kernel<128x128>') or fam.get('conv_wgrad_kernel<128, 128>'); ru = fam.get('wgrad_reduce_unpack_kernel')
+wg = fam.get('conv_wgrad_dma_kernel<128x128,SP3>') or fam.get('conv_wgrad_dma_kernel<128x128>'); ru = fam.get('wgrad_reduce_unpack_kernel')
 if wg: print("rocprof family 128x128 weight-gradient kernel: avg %.1f us over %d launches (reduce kernel avg %.1f us)" % (wg[1] / wg[0] / 1e3, wg[0], ru[1] / ru[0] / 1e3 if ru else 0))

@@ -24,6 +24,9 @@ constexpr int BK = 32;   // K-step (floats)
 constexpr int LDK = 36;  // LDS row stride (floats): 144 B keeps ds_read_b128 conflict-free
 
 constexpr int CONV_OCC = 2;   // resident workgroups per CU the forward / data-gradient kernel is compiled for
+#ifndef SPLITK_BATCH
+#define SPLITK_BATCH 1   // split-K reductions: several slabs' loads in flight per trip (0 = one slab per trip; A/B builds)
+#endif
 #ifndef SP_PIPE
 #define SP_PIPE 1      // bf16x3 direct-to-LDS weight gradient: 0 = read -> split -> MFMA in sequence inside a stage (A/B builds)
 #endif
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
       // requested before the first is added — with one slab per trip the loop was a chain of ksplit dependent L2 / HBM
       // round trips (25 us per launch at per-GPU batch 2 for 2-4 us of traffic).
       int k = 1;
-      for (; k + 3 < ksplit; k += 4) {
+      for (; SPLITK_BATCH && k + 3 < ksplit; k += 4) {
         f32x4 t[U][4];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1486,14 +1489,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* _
     // slab order (deterministic); eight slabs' loads in flight per trip instead of one (a chain of ksplit dependent round
     // trips made this kernel 21 us per launch at per-GPU batch 2)
     int k = 1;
-    for (; k + 7 < ksplit; k += 8) {
+    for (; SPLITK_BATCH && k + 7 < ksplit; k += 8) {
       f32x4 t[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) t[q] = *reinterpret_cast<const f32x4*>(part + (size_t)(k + q) * slab + src);
 #pragma unroll
       for (int q = 0; q < 8; ++q) v += t[q];
     }
-    for (; k + 1 < ksplit; k += 2) {
+    for (; SPLITK_BATCH && k + 1 < ksplit; k += 2) {
       const f32x4 t0 = *reinterpret_cast<const f32x4*>(part + (size_t)k * slab + src);
       const f32x4 t1 = *reinterpret_cast<const f32x4*>(part + (size_t)(k + 1) * slab + src);
       v += t0;
