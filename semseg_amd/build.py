@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsemseg_hip.so")
-SOURCES = ["conv_igemm.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip",
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "stem.hip", "bn.hip", "pool_interp.hip", "ce_head.hip", "psamask.hip",
            "psa_ops.hip", "infer.hip", "optim.hip", "augment.hip", "winograd.hip", "gemm_bf16split.hip", "xchg.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared"]
 
@@ -16,7 +16,8 @@ OBJ_DIR = os.path.join(CSRC, "build")          # git-ignored; objects are an inc
 
 
 def _deps(src):
-    return [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "semseg_hip.h")]
+    return [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"),
+            os.path.join(HERE, "..", "include", "semseg_hip.h")]
 
 
 def _linked_sources():
@@ -36,7 +37,7 @@ def needs_build():
 
 def build(force=False, verbose=False, defines=(), out=None):
     """One hipcc -c per source, in parallel, then one link.  Objects are cached per (source, defines) under csrc/build/ so
-    that touching one kernel file rebuilds that file only (conv_igemm.hip alone takes ~2 minutes).  `defines` / `out`
+    that touching one kernel file rebuilds that file only (conv_igemm.hip and conv_wgrad.hip take about a minute each).  `defines` / `out`
     build a VARIANT library for A/B runs (scripts/; selected with SEMSEG_HIP_LIB), never the product."""
     out = out or LIB
     if not force and not defines and out == LIB and not needs_build():
