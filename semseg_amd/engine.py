@@ -549,8 +549,8 @@ class Engine:
         dy = y.grad
         flops = 2.0 * y.M * cl.Co * cl.Ci * cl.R * cl.S
         big = cl.Ci % 128 == 0 and cl.Co >= 128
-        # 128 x 128 tiles run the direct-to-LDS kernel (conv_wgrad.hip: WGRAD_DMA_POLICY / WGRAD_SP_POLICY) — under bf16x3 its SP
-        # instance of the register-staged one — and 64 x 64 tiles the register-staged fp32 kernel
+        # 128 x 128 tiles run the direct-to-LDS kernel (conv_wgrad.hip: WGRAD_DMA_POLICY; under bf16x3 its SP = 3 form,
+        # WGRAD_SP_POLICY) and 64 x 64 tiles the register-staged fp32 kernel
         ev = self._t0(self._wgrad_family(big, cl.arith), flops)
         ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
                        cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil, arith=cl.arith)
