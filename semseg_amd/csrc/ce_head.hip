@@ -211,6 +211,16 @@ __global__ __launch_bounds__(256) void ce_bwd_cell_kernel(const float* __restric
   for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (c < C && part < PARTS) {   // CG = 40 leaves 16 idle threads (part == PARTS)
     const float* bz = z + (size_t)n * h * w * ld + c;
+    // The four low-res corners of the cell are the same for every hi-res pixel of the loop: loaded once (round 4; they were
+    // re-read per pixel — 64 B per lane and pixel through the L1, ~9 GB per launch at 150 classes and 473^2, which is what
+    // the kernel's 870 us were made of).  A pixel's interpolated score is formed from them with the SAME four products in the
+    // same order as before: its corner weights (rw, cw below) equal (1 - lh, lh) x (1 - lw, lw) except on the last low-res
+    // row / column, where the clamped index makes one weight 0 and the other 1 — adding the zero products is exact.
+    const int r1 = min(cr + 1, h - 1), c1 = min(cc + 1, w - 1);
+    const f32x4 z00 = *reinterpret_cast<const f32x4*>(bz + ((size_t)cr * w + cc) * ld);
+    const f32x4 z01 = *reinterpret_cast<const f32x4*>(bz + ((size_t)cr * w + c1) * ld);
+    const f32x4 z10 = *reinterpret_cast<const f32x4*>(bz + ((size_t)r1 * w + cc) * ld);
+    const f32x4 z11 = *reinterpret_cast<const f32x4*>(bz + ((size_t)r1 * w + c1) * ld);
     for (int q = part; q < cnt; q += PARTS) {
       const int oh = oh_lo + q / nw, ow = ow_lo + q % nw;
       int h0, h1, w0, w1;
@@ -221,11 +231,13 @@ __global__ __launch_bounds__(256) void ce_bwd_cell_kernel(const float* __restric
       const size_t px = ((size_t)n * H + oh) * W + ow;
       const long long y = label[px];
       if (y == (long long)ignore_index || y < 0 || y >= C) continue;
-      const float a00 = (1.f - lh) * (1.f - lw), a01 = (1.f - lh) * lw, a10 = lh * (1.f - lw), a11 = lh * lw;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(bz + ((size_t)h0 * w + w0) * ld) * a00 +
-                      *reinterpret_cast<const f32x4*>(bz + ((size_t)h0 * w + w1) * ld) * a01 +
-                      *reinterpret_cast<const f32x4*>(bz + ((size_t)h1 * w + w0) * ld) * a10 +
-                      *reinterpret_cast<const f32x4*>(bz + ((size_t)h1 * w + w1) * ld) * a11;
+      // weights of the cell's corner rows cr, cr+1 / columns cc, cc+1 for this pixel (h1 == h0 / w1 == w0 on the last
+      // low-res row / column)
+      const float rw0 = (h0 == cr ? 1.f - lh : 0.f) + (h1 == cr ? lh : 0.f);
+      const float rw1 = (h0 == cr + 1 ? 1.f - lh : 0.f) + (h1 == cr + 1 ? lh : 0.f);
+      const float cw0 = (w0 == cc ? 1.f - lw : 0.f) + (w1 == cc ? lw : 0.f);
+      const float cw1 = (w0 == cc + 1 ? 1.f - lw : 0.f) + (w1 == cc + 1 ? lw : 0.f);
+      const f32x4 v = z00 * (rw0 * cw0) + z01 * (rw0 * cw1) + z10 * (rw1 * cw0) + z11 * (rw1 * cw1);
       const float l = lse[px];
       f32x4 pk;
 #pragma unroll
@@ -233,12 +245,6 @@ __global__ __launch_bounds__(256) void ce_bwd_cell_kernel(const float* __restric
         pk[k] = (c + k < C) ? __expf(v[k] - l) : 0.f;
         if ((long long)(c + k) == y) pk[k] -= 1.f;
       }
-      // weights onto the cell's corner rows cr, cr+1 / cols cc, cc+1 (static register indexing;
-      // h1 == h0 / w1 == w0 on the last low-res row / column)
-      const float rw0 = (h0 == cr ? 1.f - lh : 0.f) + (h1 == cr ? lh : 0.f);
-      const float rw1 = (h0 == cr + 1 ? 1.f - lh : 0.f) + (h1 == cr + 1 ? lh : 0.f);
-      const float cw0 = (w0 == cc ? 1.f - lw : 0.f) + (w1 == cc ? lw : 0.f);
-      const float cw1 = (w0 == cc + 1 ? 1.f - lw : 0.f) + (w1 == cc + 1 ? lw : 0.f);
       a[0] += pk * (rw0 * cw0);
       a[1] += pk * (rw0 * cw1);
       a[2] += pk * (rw1 * cw0);
