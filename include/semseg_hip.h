@@ -85,10 +85,13 @@ int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx
  * layer(s) that PRODUCED this conv's input, in one kernel: dx = g = (dgrad (+ add)) * (act > 0), and
  * sums{0,1}[nslot][2*Ci] += {sum g, sum g * (y - mean) * invstd} in fp64 (slot replicas as in semseg_channel_stats).
  * Valid only when this data gradient is the last contribution to that activation's gradient.  act may be null (no
- * ReLU); bn_count 2 = bn3 + downsample BN sharing g.  Ci % 4 == 0, every ld % 4 == 0. */
+ * ReLU); relu_bits (optional, semseg_bn_apply's bit form of the same mask, Ci % 32 == 0) replaces act when given: the mask
+ * operand shrinks 32-fold (act is the largest operand of the epilogue of a 1x1 data gradient).  bn_count 2 = bn3 + downsample
+ * BN sharing g.  Ci % 4 == 0, every ld % 4 == 0. */
 int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N, int H,
                                int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad, int dil,
                                const float* add, int ldadd, int tile_n, int bn_count, const float* act, int ldact,
+                               const unsigned* relu_bits, int ldbits,
                                const float* y0, int ldy0, const float* mean0, const float* invstd0, double* sums0,
                                const float* y1, int ldy1, const float* mean1, const float* invstd1, double* sums1,
                                int nslot, int arith, float* scratch, size_t scratch_floats, hipStream_t stream);
@@ -144,9 +147,11 @@ int semseg_wino_output_transform(const float* M, int ldm, float* y, int ldy, con
                                  int dil, hipStream_t stream);
 /* The output transform of a DATA GRADIENT that completes the gradient of a BatchNorm(+ReLU) output, with that layer's
  * BatchNorm-backward reduction folded in (contract of semseg_conv_dgrad_bnreduce, one BatchNorm layer): stores
- * g = (A^T M A + add) * (act > 0) and accumulates sums[slot][2*C] += {sum g, sum g * (ybn - mean) * invstd} in fp64. */
+ * g = (A^T M A + add) * (act > 0) and accumulates sums[slot][2*C] += {sum g, sum g * (ybn - mean) * invstd} in fp64;
+ * relu_bits (optional) replaces act as there. */
 int semseg_wino_output_transform_bnreduce(const float* M, int ldm, float* y, int ldy, const float* add, int ldadd,
-                                          const float* act, int ldact, const float* ybn, int ldybn, const float* mean,
+                                          const float* act, int ldact, const unsigned* relu_bits, int ldbits,
+                                          const float* ybn, int ldybn, const float* mean,
                                           const float* invstd, double* sums, int nslot, int N, int H, int W, int C,
                                           int dil, hipStream_t stream);
 /* flip 0: U[e][co][ci] (rows_pad >= Co, Kc >= Ci);  flip 1: U[e][ci][co] with taps rotated 180 degrees (rows_pad >= Ci,
@@ -188,11 +193,14 @@ int semseg_bn_finalize(const double* stats, int nslot, double count, const float
 int semseg_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
                           const float* running_var, float eps, float* scale, float* shift, int C,
                           hipStream_t stream);
-/* out = [relu]( y*scale+shift (+ y2*scale2+shift2) (+ res) ) (* dropmask[n][c]) */
+/* out = [relu]( y*scale+shift (+ y2*scale2+shift2) (+ res) ) (* dropmask[n][c]).
+ * relu_bits (optional, [M][ldbits] 32-bit words, C % 32 == 0, ldbits >= C / 32): bit (c & 31) of word [m][c >> 5] is set where
+ * the value entering the ReLU is > 0 — the ReLU mask of torch's threshold backward at 1/32 of the activation's bytes; the fused
+ * BatchNorm-backward reductions (semseg_conv_dgrad_bnreduce, semseg_wino_output_transform_bnreduce) read it instead of out. */
 int semseg_bn_apply(const float* y, int ldy, const float* scale, const float* shift,
                     const float* y2, int ldy2, const float* scale2, const float* shift2,
                     const float* res, int ldres, const float* dropmask, float* out, int ldout,
-                    int M, int C, int HW, int relu, hipStream_t stream);
+                    int M, int C, int HW, int relu, unsigned* relu_bits, int ldbits, hipStream_t stream);
 /* g = dout (*dropmask) (*[out>0]); sums += {sum g, sum g*xhat}; g optionally written. */
 int semseg_bn_bwd_reduce(const float* dout, int lddout, const float* out, int ldout,
                          const float* dropmask, int HW, const float* y, int ldy, const float* mean,

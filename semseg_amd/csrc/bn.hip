@@ -163,6 +163,8 @@ struct ApplyArgs {
   float* out;
   int ldy, ldy2, ldres, ldout;
   int M, C, HW, relu;
+  unsigned* bits;      // optional: bit (c & 31) of word [m][c >> 5] = (value before the ReLU > 0); C % 32 == 0
+  int ldbits;
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
@@ -195,6 +197,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ApplyArgs p) {
       v += v2 * sc2 + sh2;
     }
     if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + c);
+    if (p.bits) {
+      // the 8 lanes that hold one 32-channel word of this pixel are adjacent and aligned (CV % 8 == 0, strides % 8 == 0):
+      // each contributes its 4 bits, an OR over the group assembles the word, the first lane stores it
+      const int sub = (c >> 2) & 7;
+      unsigned w = ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u))
+                   << (4 * sub);
+      w |= __shfl_xor(w, 1);
+      w |= __shfl_xor(w, 2);
+      w |= __shfl_xor(w, 4);
+      if (sub == 0) p.bits[(size_t)m * p.ldbits + (c >> 5)] = w;
+    }
     if (p.relu) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
@@ -409,12 +422,13 @@ int semseg_bn_eval_params(const float* gamma, const float* beta, const float* ru
 int semseg_bn_apply(const float* y, int ldy, const float* scale, const float* shift,
                     const float* y2, int ldy2, const float* scale2, const float* shift2,
                     const float* res, int ldres, const float* dropmask, float* out, int ldout,
-                    int M, int C, int HW, int relu, hipStream_t stream) {
+                    int M, int C, int HW, int relu, unsigned* relu_bits, int ldbits, hipStream_t stream) {
   if (!y || !scale || !shift || !out || (C & 3) || (ldy & 3) || (ldout & 3)) return SEMSEG_EINVAL;
   if (y2 && (!scale2 || !shift2 || (ldy2 & 3))) return SEMSEG_EINVAL;
   if (res && (ldres & 3)) return SEMSEG_EINVAL;
+  if (relu_bits && ((C & 31) || ldbits * 32 < C)) return SEMSEG_EINVAL;
   ApplyArgs a{y, scale, shift, y2, scale2, shift2, res, dropmask, out,
-              ldy, ldy2, ldres, ldout, M, C, HW, relu};
+              ldy, ldy2, ldres, ldout, M, C, HW, relu, relu_bits, ldbits};
   bn_apply_kernel<<<flat_grid((size_t)M * (C >> 2)), 256, 0, stream>>>(a);
   return semseg_launch_status();
 }

@@ -60,6 +60,8 @@ struct ConvArgs {
   int bnr_n;
   const float* bnr_mask;          // post-ReLU activation [M][bnr_ldm] (nullptr: no ReLU)
   int bnr_ldm;
+  const unsigned* bnr_bits;       // the same mask as bits: bit (c & 31) of word [m][c >> 5] (non-null: replaces bnr_mask)
+  int bnr_ldb;
   const float* bnr_y[2];          // pre-BN tensors [M][bnr_ldy]
   int bnr_ldy[2];
   const float* bnr_mean[2];
@@ -104,23 +106,27 @@ __device__ __forceinline__ void decode_tile(const ConvArgs& p, int tile, int& ti
 #ifndef BNR_GROUP
 #define BNR_GROUP 4      // row groups whose operand loads are in flight together (1 = the round-3 loop shape; A/B builds)
 #endif
-template <bool HAS_ADD, bool TWO>
+// BITS: the ReLU mask comes as one bit per element (written by semseg_bn_apply) instead of the post-ReLU activation itself:
+// 1/32 of the bytes of the largest operand of this epilogue.
+template <bool HAS_ADD, bool TWO, bool BITS>
 __device__ __forceinline__ void bnr_rows(const ConvArgs& p, const float* wl, float* dst, int ldd, int mrow0, int colmax,
                                          int mb, int cg, int c4, int lane, const float* add_in, const f32x4 (&bmu)[2],
                                          const f32x4 (&bis)[2], float (&bs)[2][8]) {
   constexpr int G = BNR_GROUP;
-  const bool has_mask = p.bnr_mask != nullptr;
+  const bool has_mask = !BITS && p.bnr_mask != nullptr;
   const float* maskp = has_mask ? p.bnr_mask : p.bnr_y[0];     // no ReLU: any readable tile, neutralised below
   const int ldmp = has_mask ? p.bnr_ldm : p.bnr_ldy[0];
   const int cc = cg < colmax ? cg : 0;
 #pragma nounroll
   for (int hb = 0; hb < 8 / G; ++hb) {
-    f32x4 aa[G], y0[G], dd[HAS_ADD ? G : 1], y1[TWO ? G : 1];
+    f32x4 aa[BITS ? 1 : G], y0[G], dd[HAS_ADD ? G : 1], y1[TWO ? G : 1];
+    unsigned wb[BITS ? G : 1];
 #pragma unroll
     for (int q = 0; q < G; ++q) {
       const int m = mb + (lane >> 3) + 8 * (hb * G + q);
       const size_t mm = (size_t)(m < p.M ? m : p.M - 1);
-      aa[q] = *reinterpret_cast<const f32x4*>(maskp + mm * ldmp + cc);
+      if constexpr (BITS) wb[q] = p.bnr_bits[mm * p.bnr_ldb + (cc >> 5)];
+      else aa[q] = *reinterpret_cast<const f32x4*>(maskp + mm * ldmp + cc);
       y0[q] = *reinterpret_cast<const f32x4*>(p.bnr_y[0] + mm * p.bnr_ldy[0] + cc);
       if constexpr (HAS_ADD) dd[q] = *reinterpret_cast<const f32x4*>(add_in + mm * p.ldadd + cc);
       if constexpr (TWO) y1[q] = *reinterpret_cast<const f32x4*>(p.bnr_y[1] + mm * p.bnr_ldy[1] + cc);
@@ -133,7 +139,12 @@ __device__ __forceinline__ void bnr_rows(const ConvArgs& p, const float* wl, flo
       f32x4 v = *reinterpret_cast<const f32x4*>(&wl[lr * LDK + c4]);
       if constexpr (HAS_ADD) v += dd[q];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = ((!has_mask || aa[q][k] > 0.f) && ok) ? v[k] : 0.f;
+      for (int k = 0; k < 4; ++k) {
+        bool keep;
+        if constexpr (BITS) keep = (wb[q] >> ((cc & 31) + k)) & 1u;
+        else keep = !has_mask || aa[q][k] > 0.f;
+        v[k] = (keep && ok) ? v[k] : 0.f;
+      }
       const f32x4 xh0 = (y0[q] - bmu[0]) * bis[0];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -233,10 +244,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[2
         const bool has_add = add_in != nullptr, two = p.bnr_n > 1;
         // one specialised copy of the row loop per (residual add, second BatchNorm) combination: a wave-uniform switch
         // outside the loop instead of aliased or guarded loads inside it
-        if (has_add && two) bnr_rows<true, true>(p, wl, dst, ldd, mrow0, colmax, mb, cg, c4, lane, add_in, bmu, bis, bs);
-        else if (has_add) bnr_rows<true, false>(p, wl, dst, ldd, mrow0, colmax, mb, cg, c4, lane, add_in, bmu, bis, bs);
-        else if (two) bnr_rows<false, true>(p, wl, dst, ldd, mrow0, colmax, mb, cg, c4, lane, add_in, bmu, bis, bs);
-        else bnr_rows<false, false>(p, wl, dst, ldd, mrow0, colmax, mb, cg, c4, lane, add_in, bmu, bis, bs);
+#define BNR_CALL(A_, T_, B_) bnr_rows<A_, T_, B_>(p, wl, dst, ldd, mrow0, colmax, mb, cg, c4, lane, add_in, bmu, bis, bs)
+        if (p.bnr_bits) {
+          if (has_add && two) BNR_CALL(true, true, true);
+          else if (has_add) BNR_CALL(true, false, true);
+          else if (two) BNR_CALL(false, true, true);
+          else BNR_CALL(false, false, true);
+        } else {
+          if (has_add && two) BNR_CALL(true, true, false);
+          else if (has_add) BNR_CALL(true, false, false);
+          else if (two) BNR_CALL(false, true, false);
+          else BNR_CALL(false, false, false);
+        }
+#undef BNR_CALL
       } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -700,6 +720,7 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
 struct BnrArgs {   // fused BatchNorm-backward reduction (see ConvArgs::bnr_*); pointers already at the first row handled
   int n;
   const float* mask; int ldm;
+  const unsigned* bits; int ldb;     // the mask as bits (non-null: replaces mask)
   const float* y[2]; int ldy[2];
   const float* mean[2]; const float* invstd[2];
   double* sums[2];
@@ -797,7 +818,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
             for (int k = 0; k < 4; ++k) r[k] = fmaxf(r[k], 0.f);
           }
           if (bn.n > 0) {
-            if (bn.mask) {
+            if (bn.bits) {
+              const unsigned wq = bn.bits[(size_t)m * bn.ldb + (c >> 5)] >> (c & 31);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) r[k] = ((wq >> k) & 1u) ? r[k] : 0.f;
+            } else if (bn.mask) {
               const f32x4 a4 = *reinterpret_cast<const f32x4*>(bn.mask + (size_t)m * bn.ldm + c);
 #pragma unroll
               for (int k = 0; k < 4; ++k) r[k] = a4[k] > 0.f ? r[k] : 0.f;
@@ -1105,6 +1130,8 @@ static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, int ar
     bn.n = a.bnr_n;
     bn.mask = (a.bnr_n && a.bnr_mask) ? a.bnr_mask + (size_t)p.tail_m0 * a.bnr_ldm : nullptr;
     bn.ldm = a.bnr_ldm;
+    bn.bits = (a.bnr_n && a.bnr_bits) ? a.bnr_bits + (size_t)p.tail_m0 * a.bnr_ldb : nullptr;
+    bn.ldb = a.bnr_ldb;
     for (int b = 0; b < 2; ++b) {
       const bool on = b < a.bnr_n;
       bn.y[b] = on ? a.bnr_y[b] + (size_t)p.tail_m0 * a.bnr_ldy[b] : nullptr;
@@ -1134,7 +1161,7 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
   a.N = N; a.Hin = H; a.Win = W; a.Hout = Ho; a.Wout = Wo;
   a.Kc = Ci; a.Nout = Co; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * Ho * Wo; a.tiles_n = 0; a.stats_nslot = stats_nslot > 0 ? stats_nslot : 1;
-  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0; a.bnr_n = 0; a.bnr_mask = nullptr;
+  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0; a.bnr_n = 0; a.bnr_mask = nullptr; a.bnr_bits = nullptr;
   return conv_launch(false, a, tile_n, arith, scratch, scratch_floats, stream);
 }
 
@@ -1151,9 +1178,9 @@ static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx
   a.N = N; a.Hin = Ho; a.Win = Wo; a.Hout = H; a.Wout = W;
   a.Kc = Kc; a.Nout = Ci; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * H * W; a.tiles_n = 0; a.stats_nslot = 1;
-  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0; a.bnr_n = 0; a.bnr_mask = nullptr;
+  a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0; a.bnr_n = 0; a.bnr_mask = nullptr; a.bnr_bits = nullptr;
   if (bnr) {
-    a.bnr_n = bnr->bnr_n; a.bnr_mask = bnr->bnr_mask; a.bnr_ldm = bnr->bnr_ldm; a.stats_nslot = bnr->stats_nslot;
+    a.bnr_n = bnr->bnr_n; a.bnr_mask = bnr->bnr_mask; a.bnr_ldm = bnr->bnr_ldm; a.bnr_bits = bnr->bnr_bits; a.bnr_ldb = bnr->bnr_ldb; a.stats_nslot = bnr->stats_nslot;
     for (int b = 0; b < 2; ++b) {
       a.bnr_y[b] = bnr->bnr_y[b]; a.bnr_ldy[b] = bnr->bnr_ldy[b]; a.bnr_mean[b] = bnr->bnr_mean[b];
       a.bnr_invstd[b] = bnr->bnr_invstd[b]; a.bnr_sums[b] = bnr->bnr_sums[b];
@@ -1177,6 +1204,7 @@ int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx
 int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N, int H,
                                int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad, int dil,
                                const float* add, int ldadd, int tile_n, int bn_count, const float* act, int ldact,
+                               const unsigned* relu_bits, int ldbits,
                                const float* y0, int ldy0, const float* mean0, const float* invstd0, double* sums0,
                                const float* y1, int ldy1, const float* mean1, const float* invstd1, double* sums1,
                                int nslot, int arith, float* scratch, size_t scratch_floats, hipStream_t stream) {
@@ -1184,10 +1212,11 @@ int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, 
   if (bn_count == 2 && (!y1 || !mean1 || !invstd1 || !sums1)) return SEMSEG_EINVAL;
   // the fused path lives in the 16-byte store phase of the epilogue: everything 4-float aligned, channels % 4 == 0
   if ((Ci & 3) || (lddx & 3) || lddx < Ci || (ldy0 & 3) || (act && (ldact & 3)) || (add && (ldadd & 3)) ||
-      (bn_count == 2 && (ldy1 & 3)))
+      (bn_count == 2 && (ldy1 & 3)) || (relu_bits && ((Ci & 31) || ldbits * 32 < Ci)))
     return SEMSEG_EINVAL;
   ConvArgs b;
-  b.bnr_n = bn_count; b.bnr_mask = act; b.bnr_ldm = ldact; b.stats_nslot = nslot;
+  b.bnr_n = bn_count; b.bnr_mask = relu_bits ? nullptr : act; b.bnr_ldm = ldact; b.stats_nslot = nslot;
+  b.bnr_bits = relu_bits; b.bnr_ldb = ldbits;
   b.bnr_y[0] = y0; b.bnr_ldy[0] = ldy0; b.bnr_mean[0] = mean0; b.bnr_invstd[0] = invstd0; b.bnr_sums[0] = sums0;
   b.bnr_y[1] = y1; b.bnr_ldy[1] = ldy1; b.bnr_mean[1] = mean1; b.bnr_invstd[1] = invstd1; b.bnr_sums[1] = sums1;
   return dgrad_impl(dy, lddy, w_dgrad, dx, lddx, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, add, ldadd, tile_n,
@@ -1208,7 +1237,7 @@ int semseg_gemm_rows_batched(const float* a, int lda, long long a_bs, const floa
   g.N = 1; g.Hin = M; g.Win = 1; g.Hout = M; g.Wout = 1;
   g.Kc = K; g.Nout = Nout; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.dil = 1;
   g.M = M; g.tiles_n = 0; g.stats_nslot = 1;
-  g.batch = batch; g.x_bs = a_bs; g.w_bs = bt_bs; g.y_bs = c_bs; g.add_bs = 0; g.bnr_n = 0; g.bnr_mask = nullptr;
+  g.batch = batch; g.x_bs = a_bs; g.w_bs = bt_bs; g.y_bs = c_bs; g.add_bs = 0; g.bnr_n = 0; g.bnr_mask = nullptr; g.bnr_bits = nullptr;
   return conv_launch(false, g, Nout >= 128 ? 128 : 64, arith, nullptr, 0, stream);
 }
 

@@ -159,6 +159,8 @@ struct WinoOutArgs {
   int relu;
   int bnr;
   const float* act;      // post-ReLU activation (nullptr: no ReLU)
+  const unsigned* bits;  // the ReLU mask as bits (semseg_bn_apply's relu_bits; non-null: replaces act)
+  int ldbits;
   const float* ybn;      // pre-BatchNorm tensor
   const float* mean;
   const float* invstd;
@@ -216,7 +218,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs p) {
           const size_t pix = (size_t)(n * g.H + y) * g.W + x;
           if (p.bnr) {
             if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + pix * p.ldadd + c);
-            if (p.act) {
+            if (p.bits) {
+              const unsigned wq = p.bits[pix * p.ldbits + (c >> 5)] >> (c & 31);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = ((wq >> k) & 1u) ? v[k] : 0.f;
+            } else if (p.act) {
               const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.act + pix * p.ldact + c);
 #pragma unroll
               for (int k = 0; k < 4; ++k) v[k] = a4[k] > 0.f ? v[k] : 0.f;
@@ -431,22 +437,24 @@ int semseg_wino_output_transform(const float* M, int ldm, float* y, int ldy, con
   a.M = M; a.y = y; a.add = add; a.stats = stats; a.ldm = ldm; a.ldy = ldy; a.ldadd = ldadd; a.C = C;
   a.nslot = nslot > 0 ? nslot : 1;
   a.g = make_geo(N, H, W, dil);
-  a.bnr = 0; a.act = nullptr; a.ybn = nullptr; a.mean = nullptr; a.invstd = nullptr; a.ldact = 0; a.ldybn = 0;
+  a.bnr = 0; a.act = nullptr; a.bits = nullptr; a.ldbits = 0; a.ybn = nullptr; a.mean = nullptr; a.invstd = nullptr; a.ldact = 0; a.ldybn = 0;
   a.scale = scale; a.shift = shift; a.relu = relu;
   return launch_output(a, stream);
 }
 
 int semseg_wino_output_transform_bnreduce(const float* M, int ldm, float* y, int ldy, const float* add, int ldadd,
-                                          const float* act, int ldact, const float* ybn, int ldybn, const float* mean,
+                                          const float* act, int ldact, const unsigned* relu_bits, int ldbits,
+                                          const float* ybn, int ldybn, const float* mean,
                                           const float* invstd, double* sums, int nslot, int N, int H, int W, int C,
                                           int dil, hipStream_t stream) {
   if (!M || !y || !ybn || !mean || !invstd || !sums || nslot < 1 || (C & 3) || (ldm & 3) || (ldy & 3) || ldm < C ||
-      ldy < C || (add && (ldadd & 3)) || (act && (ldact & 3)) || (ldybn & 3) || semseg_wino_tiles(N, H, W, dil) < 0)
+      ldy < C || (add && (ldadd & 3)) || (act && (ldact & 3)) || (ldybn & 3) || semseg_wino_tiles(N, H, W, dil) < 0 ||
+      (relu_bits && ((C & 31) || ldbits * 32 < C)))
     return SEMSEG_EINVAL;
   WinoOutArgs a;
   a.M = M; a.y = y; a.add = add; a.stats = sums; a.ldm = ldm; a.ldy = ldy; a.ldadd = ldadd; a.C = C; a.nslot = nslot;
   a.g = make_geo(N, H, W, dil);
-  a.bnr = 1; a.act = act; a.ybn = ybn; a.mean = mean; a.invstd = invstd; a.ldact = ldact; a.ldybn = ldybn;
+  a.bnr = 1; a.act = relu_bits ? nullptr : act; a.bits = relu_bits; a.ldbits = ldbits; a.ybn = ybn; a.mean = mean; a.invstd = invstd; a.ldact = ldact; a.ldybn = ldybn;
   a.scale = nullptr; a.shift = nullptr; a.relu = 0;
   return launch_output(a, stream);
 }

@@ -91,7 +91,8 @@ class TapeOp:
 
 class Act:
     """NHWC activation view: `data` starts at the first valid channel; `ld` = channel stride."""
-    __slots__ = ("data", "N", "H", "W", "C", "ld", "grad", "ginit", "name", "bnsrc", "fuse_ok", "pending", "bn_reduced")
+    __slots__ = ("data", "N", "H", "W", "C", "ld", "grad", "ginit", "name", "bnsrc", "fuse_ok", "pending", "bn_reduced",
+                 "bits")
 
     def __init__(self, data, N, H, W, C, ld, name=""):
         self.data, self.N, self.H, self.W, self.C, self.ld = data, N, H, W, C, ld
@@ -103,6 +104,7 @@ class Act:
         # are still outstanding in backward, and whether the last one already did the reduction
         self.bnsrc = None
         self.fuse_ok = False
+        self.bits = None       # ReLU mask of a BatchNorm+ReLU output as bits [M][C / 32] (bn_act, training)
         self.pending = 0
         self.bn_reduced = False
 
@@ -130,6 +132,9 @@ ARITH = _ARITH_NAMES[os.environ.get("SEMSEG_ARITH", "bf16x3")]
 # tiles, csrc/gemm_bf16split.hip; 197 vs 182 TFLOP/s fp32-equivalent on cls.0) or "igemm" (the SP instances of
 # conv_igemm_kernel that the 1x1 convs run)
 WINO_BF16X3_KERNEL = os.environ.get("SEMSEG_WINO_GEMM", "standalone")
+# SEMSEG_RELU_BITS=0: the fused BatchNorm-backward reductions read the post-ReLU activation as their mask (rounds 2-3) instead
+# of the bit mask bn_apply writes next to it
+RELU_BITS = os.environ.get("SEMSEG_RELU_BITS", "1") != "0"
 
 
 def set_arith(name):
@@ -610,7 +615,7 @@ class Engine:
                                         x.data if bs["relu"] else None, x.ld,
                                         [(yk.data, yk.ld, blk.mean, blk.invstd, blk.sums) for yk, blk in bs["bns"]],
                                         ops.NSLOT, add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch(),
-                                        arith=ar)
+                                        arith=ar, relu_bits=x.bits if bs["relu"] else None)
                 x.bn_reduced = True
             else:
                 ops.conv_dgrad(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
@@ -647,11 +652,11 @@ class Engine:
                           2.0 * 16 * T * Nout * K)
             ops.gemm_rows_batched(V, K, T * K, U, rows_pad * K, Mb, Nout, T * Nout, T, K, Nout, 16, arith=arith)
         self._t1(ev)
-        ev = self._t0(WINO_HBM, -4.0 * (16 * T * Nout + px * Nout * (1 + (add is not None) + (2 if bnr else 0))))
+        ev = self._t0(WINO_HBM, -4.0 * (16 * T * Nout + px * Nout * (1 + (add is not None) + ((1 + (1.0 if bnr[7] is None else 1.0 / 32)) if bnr else 0))))
         if bnr is not None:
-            act, ldact, ybn, ldybn, mean, invstd, sums = bnr
+            act, ldact, ybn, ldybn, mean, invstd, sums, bits = bnr
             ops.wino_output_transform_bnreduce(Mb, Nout, dst, ldd, N, H, W, Nout, d, act, ldact, ybn, ldybn, mean,
-                                               invstd, sums, ops.NSLOT, add=add, ldadd=ldadd)
+                                               invstd, sums, ops.NSLOT, add=add, ldadd=ldadd, relu_bits=bits)
         else:
             sc, sh, relu = fold if fold is not None else (None, None, False)
             ops.wino_output_transform(Mb, Nout, dst, ldd, N, H, W, Nout, d, add=add, ldadd=ldadd, stats=stats,
@@ -701,7 +706,8 @@ class Engine:
             if (self.fuse_bnr and last and bs is not None and len(bs["bns"]) == 1 and x.C % 4 == 0 and x.ld % 4 == 0
                     and bs["bns"][0][0].ld % 4 == 0):
                 yk, blk = bs["bns"][0]
-                bnr = (x.data if bs["relu"] else None, x.ld, yk.data, yk.ld, blk.mean, blk.invstd, blk.sums)
+                bnr = (x.data if bs["relu"] else None, x.ld, yk.data, yk.ld, blk.mean, blk.invstd, blk.sums,
+                       x.bits if bs["relu"] else None)
             self._wino_rows(dy, y.ld, cl.wino.Kc, cl.wino.U_dgrad, cl.wino.Ci_pad, gx, x.ld, cl.Ci, N, H, W, d, T,
                             self._wino_scratch("Vdy", 16 * T * cl.wino.Kc), add=gx if x.ginit else None, ldadd=x.ld,
                             bnr=bnr, arith=cl.arith)
@@ -861,11 +867,15 @@ class Engine:
             cnt = self.bn_prepare(bm, y.M) if prepared is None else prepared
         if out is None:
             out = self.act(y.N, y.H, y.W, y.C, tag="bnact")
+        # The ReLU mask as bits: what the fused BatchNorm-backward reductions read in backward instead of the activation
+        # itself (1/32 of its bytes; the activation is the largest operand of a 1x1 data gradient's epilogue).
+        if RELU_BITS and self.training and relu and dropmask is None and y.C % 32 == 0:
+            out.bits = self.buf((y.M, y.C // 32), dtype=torch.int32, tag="relubits")
         ops.bn_apply(y.data, y.ld, bl.scale, bl.shift, out.data, out.ld, y.M, y.C, y.H * y.W, relu,
                      y2=None if y2 is None else y2.data, ldy2=0 if y2 is None else y2.ld,
                      scale2=None if bl2 is None else bl2.scale, shift2=None if bl2 is None else bl2.shift,
                      res=None if res is None else res.data, ldres=0 if res is None else res.ld,
-                     dropmask=dropmask)
+                     dropmask=dropmask, relu_bits=out.bits)
         if self.training:
             if dropmask is None:
                 out.bnsrc = dict(bns=[(y, bl)] + ([(y2, bl2)] if y2 is not None else []), relu=relu)

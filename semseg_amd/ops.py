@@ -207,9 +207,9 @@ def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldad
 
 
 def conv_dgrad_bnreduce(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, act, ldact, bns, nslot, add=None, ldadd=0,
-                        scratch=None, arith=ARITH_F32):
+                        scratch=None, arith=ARITH_F32, relu_bits=None):
     """Data gradient fused with the BatchNorm-backward reduction of the layer(s) that produced the conv's input.
-    bns: 1 or 2 tuples (y, ldy, mean, invstd, sums[nslot][2*Ci])."""
+    bns: 1 or 2 tuples (y, ldy, mean, invstd, sums[nslot][2*Ci]).  relu_bits: bn_apply's bit mask, read instead of act."""
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
     b0 = bns[0]
@@ -217,6 +217,7 @@ def conv_dgrad_bnreduce(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, act, 
     tile = _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch, arith)
     _ck(lib.semseg_conv_dgrad_bnreduce(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R,
                                        pk.S, stride, pad, dil, _p(add), ldadd, tile, len(bns), _p(act), ldact,
+                                       _p(relu_bits), 0 if relu_bits is None else relu_bits.shape[-1],
                                        _p(b0[0]), b0[1], _p(b0[2]), _p(b0[3]), _p(b0[4]),
                                        _p(b1[0]), b1[1], _p(b1[2]), _p(b1[3]), _p(b1[4]), nslot, arith, *_scr(scratch),
                                        _stream()), "conv_dgrad_bnreduce")
@@ -275,8 +276,9 @@ def wino_output_transform(M, ldm, y, ldy, N, H, W, C, dil, add=None, ldadd=0, st
 
 
 def wino_output_transform_bnreduce(M, ldm, y, ldy, N, H, W, C, dil, act, ldact, ybn, ldybn, mean, invstd, sums, nslot,
-                                   add=None, ldadd=0):
-    _ck(lib.semseg_wino_output_transform_bnreduce(_p(M), ldm, _p(y), ldy, _p(add), ldadd, _p(act), ldact, _p(ybn), ldybn,
+                                   add=None, ldadd=0, relu_bits=None):
+    _ck(lib.semseg_wino_output_transform_bnreduce(_p(M), ldm, _p(y), ldy, _p(add), ldadd, _p(act), ldact, _p(relu_bits),
+                                                  0 if relu_bits is None else relu_bits.shape[-1], _p(ybn), ldybn,
                                                   _p(mean), _p(invstd), _p(sums), nslot, N, H, W, C, dil, _stream()),
         "wino_output_transform_bnreduce")
 
@@ -366,10 +368,11 @@ def bn_eval_params(gamma, beta, rm, rv, eps, scale, shift, C):
 
 
 def bn_apply(y, ldy, scale, shift, out, ldout, M, C, HW, relu, y2=None, ldy2=0, scale2=None,
-             shift2=None, res=None, ldres=0, dropmask=None):
+             shift2=None, res=None, ldres=0, dropmask=None, relu_bits=None):
+    """relu_bits: optional int32 [M][C / 32] tensor receiving the ReLU mask as bits (include/semseg_hip.h)."""
     _ck(lib.semseg_bn_apply(_p(y), ldy, _p(scale), _p(shift), _p(y2), ldy2, _p(scale2), _p(shift2),
                             _p(res), ldres, _p(dropmask), _p(out), ldout, M, C, HW, int(relu),
-                            _stream()), "bn_apply")
+                            _p(relu_bits), 0 if relu_bits is None else relu_bits.shape[-1], _stream()), "bn_apply")
 
 
 def bn_bwd_reduce(dout, lddout, out, ldout, dropmask, HW, y, ldy, mean, invstd, g, ldg, sums, M, C,

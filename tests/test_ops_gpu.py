@@ -21,6 +21,14 @@ def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
+def relu_bits(act_nhwc):
+    """The ReLU mask of an NHWC activation as semseg_bn_apply writes it: int32 [M][C / 32], bit (c & 31) of word [m][c >> 5]."""
+    C = act_nhwc.shape[-1]
+    m = (act_nhwc.reshape(-1, C // 32, 32) > 0).to(torch.int64)
+    w = (m << torch.arange(32, device=m.device)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+
+
 def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
@@ -49,9 +57,10 @@ CONV_CASES = [
     (7, 60, 60, 128, 64, 1, 1, 0, 1, 1, True, True),        # 197 m-tiles: full tiles AND a split tail in one launch
     (2, 21, 21, 64, 128, 3, 2, 1, 1, 1, False, False),      # 64-wide tile, strided conv
 ])
-def test_conv_dgrad_fused_bn_backward_reduce(case, report):
+@pytest.mark.parametrize("mask", ["act", "bits"])
+def test_conv_dgrad_fused_bn_backward_reduce(case, mask, report):
     """semseg_conv_dgrad_bnreduce: dx = (dgrad (+ add)) * (act > 0) and fp64 [sum g, sum g * xhat] per channel for one
-    or two BatchNorm layers, against the unfused formula in fp64."""
+    or two BatchNorm layers, against the unfused formula in fp64; the ReLU mask given as the activation or as bits."""
     from semseg_amd import ops
     N, H, W, Ci, Co, k, s, p, d, nbn, with_add, split = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
@@ -77,8 +86,10 @@ def test_conv_dgrad_fused_bn_backward_reduce(case, report):
     sums = [torch.zeros(NS * 2 * Ci, dtype=torch.float64, device=DEV) for _ in range(nbn)]
     bns = [(nhwc(ys[b]).to(DEV).contiguous(), Ci, means[b].to(DEV), invs[b].to(DEV), sums[b]) for b in range(nbn)]
     scratch = torch.empty(16 * 1024 * 1024, device=DEV) if split else None
-    ops.conv_dgrad_bnreduce(dyb, ldy, pk, dxb, Ci, N, H, W, s, p, d, nhwc(act).to(DEV).contiguous(), Ci, bns, NS,
-                            add=dxb if with_add else None, ldadd=Ci, scratch=scratch)
+    actb = nhwc(act).to(DEV).contiguous()
+    ops.conv_dgrad_bnreduce(dyb, ldy, pk, dxb, Ci, N, H, W, s, p, d, actb if mask == "act" else None, Ci, bns, NS,
+                            add=dxb if with_add else None, ldadd=Ci, scratch=scratch,
+                            relu_bits=relu_bits(actb) if mask == "bits" else None)
     e_g = relerr(nchw(dxb), g64)
     errs = []
     for b in range(nbn):
@@ -86,7 +97,7 @@ def test_conv_dgrad_fused_bn_backward_reduce(case, report):
         xh = (ys[b].double() - means[b].double().view(1, -1, 1, 1)) * invs[b].double().view(1, -1, 1, 1)
         errs.append(relerr(tot[:Ci], g64.sum((0, 2, 3))))
         errs.append(relerr(tot[Ci:], (g64 * xh).sum((0, 2, 3))))
-    report("fused dgrad + BN-backward reduce %s: g %.2e sums %s" % (case, e_g, " ".join("%.1e" % e for e in errs)))
+    report("fused dgrad + BN-backward reduce %s mask=%s: g %.2e sums %s" % (case, mask, e_g, " ".join("%.1e" % e for e in errs)))
     assert e_g < 2e-5 and max(errs) < 2e-5
 
 
@@ -300,6 +311,32 @@ def test_bn_train_fwd_bwd(C, HW, mode, report):
         errs.append(relerr(nchw(dy2), y2.grad))
     report("bn C=%d HW=%d %s: %s" % (C, HW, mode, " ".join("%.2e" % e for e in errs)))
     assert max(errs) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(3, 7, 9, 64), (2, 15, 15, 256), (1, 5, 5, 2048)])
+@pytest.mark.parametrize("form", ["plain", "res", "two"])
+def test_bn_apply_relu_bits(shape, form, report):
+    """semseg_bn_apply's optional bit output: bit (c & 31) of word [m][c >> 5] = (the value entering the ReLU > 0), for the
+    three forms the engine uses (BatchNorm+ReLU, + residual, bn3 + downsample BN); the activation itself is unchanged."""
+    from semseg_amd import ops
+    N, H, W, C = shape
+    M = N * H * W
+    g = torch.Generator().manual_seed(C + len(form))
+    y = torch.randn(M, C, generator=g).to(DEV)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    y2 = torch.randn(M, C, generator=g).to(DEV) if form == "two" else None
+    sc2, sh2 = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    res = torch.randn(M, C, generator=g).to(DEV) if form == "res" else None
+    out0 = torch.empty(M, C, device=DEV)
+    out1 = torch.empty(M, C, device=DEV)
+    bits = torch.full((M, C // 32), -1, dtype=torch.int32, device=DEV)
+    kw = dict(y2=y2, ldy2=C, scale2=sc2 if y2 is not None else None, shift2=sh2 if y2 is not None else None, res=res,
+              ldres=C)
+    ops.bn_apply(y, C, sc, sh, out0, C, M, C, H * W, True, **kw)
+    ops.bn_apply(y, C, sc, sh, out1, C, M, C, H * W, True, relu_bits=bits, **kw)
+    assert torch.equal(out0, out1)
+    assert torch.equal(bits, relu_bits(out1))
+    assert 0.2 < float((out1 > 0).float().mean()) < 0.8
 
 
 def test_bn_eval(report):
@@ -833,6 +870,15 @@ def test_winograd_conv_fwd_dgrad_wgrad(case, arith, report):
     e_g = relerr(gb[..., 16:16 + Ci], g_ref)
     e_gs = float((sums.view(ops.NSLOT, 2, Ci).sum(0).cpu() - s_ref).abs().max() / s_ref.abs().max())
     assert e_g < 2e-5 and e_gs < 1e-5, (e_g, e_gs)
+    if Ci % 32 == 0:    # the same with the mask as bits (what bn_apply writes): identical values
+        sums_b = torch.zeros_like(sums)
+        gb2 = torch.full((N, H, W, ldx), float("nan"), device=DEV)
+        ops.wino_output_transform_bnreduce(Mbuf, Ci, gb2[..., 16:], ldx, N, H, W, Ci, d, None, 0, ybn, Ci + 4, mean,
+                                           invstd, sums_b, ops.NSLOT, add=base[..., 16:], ldadd=ldx,
+                                           relu_bits=relu_bits(act[..., 16:16 + Ci]))
+        assert torch.equal(gb2[..., 16:16 + Ci], gb[..., 16:16 + Ci])
+        sa, sb = sums.view(ops.NSLOT, 2, Ci).sum(0), sums_b.view(ops.NSLOT, 2, Ci).sum(0)
+        assert float((sa - sb).abs().max() / sa.abs().max()) < 1e-12
     # weight gradient from the kept transformed input
     Yh = torch.zeros(16 * T * ops.roundup(Co, 128), device=DEV)
     dU = torch.empty(16 * Co * Ci, device=DEV)
