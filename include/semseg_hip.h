@@ -221,7 +221,7 @@ int semseg_bn_param_grads(double* sums, int nslot, float* dgamma, float* dbeta, 
  * (hipIpcMemHandle_t, 64 bytes) and maps every peer's (semseg_xchg_ipc_import); peer_bases = HOST array of the `world`
  * mapped base pointers in rank order (own buffer at [rank]).  allreduce: out[0:n] = sum over ranks of (sum over the nslot
  * replicas of in[nslot][n]), summed in rank order on every rank (bit-identical results); seq = 1, 2, ... must advance by
- * one per call, identically on every rank; n <= SEMSEG_XCHG_MAX_DOUBLES.  A rank whose peers do not arrive within ~1 s sets
+ * one per call, identically on every rank; n <= SEMSEG_XCHG_MAX_DOUBLES.  A rank whose peers do not arrive within 20 s sets
  * *err_dev = 1 and returns garbage in out (the caller checks err_dev).  OPT-IN path: verified with several processes on
  * one GPU only (round 4), RCCL stays the default exchange. */
 #define SEMSEG_XCHG_MAX_DOUBLES 16384

@@ -1,6 +1,7 @@
 """Regenerate semseg_amd/tile_table.json on an MI355X: for every forward / data-gradient shape of the BASELINE.json
 configurations (PSPNet-101 473^2 at per-GPU batch 16 / 8 / 4 / 2, PSANet-101 465^2 at 16 / 2, PSPNet-101 713^2 at 2)
-time the four tile shapes (128 x 128, 128 x 64, 64 x 128, 64 x 64) on real operands (semseg_amd.ops._tuned_tile, 3
+time the four tile shapes (128 x 128, 128 x 64, 64 x 128, 64 x 64; with --split also code 2128 = the 256 x 128 bf16x3 GEMM
+kernel for the forward of 1x1 stride-1 convs) on real operands (semseg_amd.ops._tuned_tile, 3
 interleaved rounds of 3 launches, device idle) and keep 128 x 128 unless another shape wins by >= 3 %.  The table is committed; nothing times tiles at run time.
 
     SEMSEG_TILE_TUNE=1 python scripts/make_tile_table.py [out.json]        (GPU box; copy the result into semseg_amd/)
@@ -50,11 +51,12 @@ if __name__ == "__main__":
         torch.cuda.empty_cache()
     tiles = dict(sorted((k, v) for k, v in ops.TILE_CHOICE.items() if k.endswith("|sp") == SPLIT))
     doc = {"generated_by": "scripts/make_tile_table.py (3 x 3 launches per tile shape; 128 x 128 unless another wins by >= 3 %)",
-           "tile_codes": "128 = 128x128, 64 = 128x64, 1128 = 64x128, 1064 = 64x64 (rows x columns)",
+           "tile_codes": "128 = 128x128, 64 = 128x64, 1128 = 64x128, 1064 = 64x64 (rows x columns); 2128 = forward of a 1x1 "
+                         "stride-1 conv on the 256x128 bf16x3 GEMM kernel (gemm_bf16split.hip)",
            "configs": ["%s%d_%d_c%d_bs%d" % c for c in CONFIGS],
            "tiles": tiles,
            "ms_per_tile_code": {k: {str(c): t for c, t in v.items()} for k, v in sorted(ops.TILE_TIMES.items())}}
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as f:
         json.dump(doc, f, indent=0, sort_keys=False)
-    print("wrote %s: %d shapes, by tile code %s" % (out, len(tiles), {c: sum(1 for v in tiles.values() if v == c) for c in ops.TILE_CODES}))
+    print("wrote %s: %d shapes, by tile code %s" % (out, len(tiles), {c: sum(1 for v in tiles.values() if v == c) for c in ops.TILE_CODES + (ops.TILE_SPLIT_GEMM,)}))

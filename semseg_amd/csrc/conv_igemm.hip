@@ -13,6 +13,7 @@
 // 32x32 MFMA blocks; global->register prefetch of K-step t+1 overlaps the MFMAs of step t.
 // (The weight gradient lives in conv_wgrad.hip since round 4.)
 #include "conv_common.h"
+#include "gemm_bf16split.h"
 
 namespace {
 
@@ -1008,7 +1009,8 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 // tile code of the C ABI: 128 / 64 = 128-row tiles, that many output columns; 1128 / 1064 = 64-row tiles (2 waves), for
 // launches whose 128-row grid would not fill the chip (small per-GPU batch) — 4x the tiles of a 128 x 128 grid without
 // splitting K, so no partial slabs and no separate epilogue pass
-static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064 || t == 1128; }
+// 2128: the 256 x 128 bf16x3 GEMM kernel of gemm_bf16split.hip for eligible 1x1 forward convs (semseg_conv_fwd), else 128
+static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064 || t == 1128 || t == 2128; }
 
 
 // arith (include/semseg_hip.h): SEMSEG_ARITH_BF16X3 selects the SP = 3 instances of the 1x1 / 3x3 buffer-load kernels
@@ -1162,6 +1164,14 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
   a.Kc = Ci; a.Nout = Co; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * Ho * Wo; a.tiles_n = 0; a.stats_nslot = stats_nslot > 0 ? stats_nslot : 1;
   a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0; a.bnr_n = 0; a.bnr_mask = nullptr; a.bnr_bits = nullptr;
+  if (tile_n == 2128) {
+    // the 256 x 128 bf16x3 GEMM kernel (gemm_bf16split.hip) for what is a plain row GEMM with statistics: 1x1, stride 1, no
+    // padding, nothing folded into the epilogue, whole 128-column panels; anything else runs the 128 x 128 implicit-GEMM tile
+    const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W && !bias && !scale && !relu && !add;
+    if (arith == SEMSEG_ARITH_BF16X3 && plain && Co % 128 == 0 && (ldy & 3) == 0 && ldy >= Co && ((size_t)y & 15) == 0)
+      return semseg_split_gemm_conv1x1_fwd(x, ldx, w_fwd, y, ldy, a.M, Ci, Co, stats, a.stats_nslot, stream);
+    tile_n = 128;
+  }
   return conv_launch(false, a, tile_n, arith, scratch, scratch_floats, stream);
 }
 
@@ -1170,6 +1180,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx
                       int pad, int dil, const float* add, int ldadd, int tile_n, int arith, const ConvArgs* bnr,
                       float* scratch, size_t scratch_floats, hipStream_t stream) {
   if (!dy || !w_dgrad || !dx || (lddy & 3) || !tile_code_ok(tile_n) || !arith_ok(arith)) return SEMSEG_EINVAL;
+  if (tile_n == 2128) tile_n = 128;
   const int Kc = (Co + 31) / 32 * 32;
   if (lddy < Kc) return SEMSEG_EINVAL;
   ConvArgs a;

@@ -15,6 +15,7 @@
 // fragments.  Measured and set aside in round 3 (git history, commit 9e79bfe: csrc/experiments/gemm_bf16split_256sq.inc): a
 // 256 x 256 tile with a deeper pipeline ran the six-product form in the same time.
 #include "common.h"
+#include "gemm_bf16split.h"
 #include "../../include/semseg_hip.h"
 
 namespace {
@@ -31,6 +32,8 @@ struct SplitArgs {
   float* c;
   long long a_bs, bt_bs, c_bs;
   int lda, ldc, M, K, Nout, tiles_m, tiles_n, total;
+  double* stats;        // EPI 1: [nslot][2 * Nout] fp64 {sum, sum of squares} per column of C (semseg_conv_fwd's statistics)
+  int nslot;
 };
 
 // x -> NS bf16 pieces (round to nearest even at every level; the remainders are exact in fp32)
@@ -44,7 +47,10 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[NS]) {
   }
 }
 
-template <int NS, int BK>
+// EPI 0: C is stored (the batched row GEMM of the Winograd path).  EPI 1: a 1x1 stride-1 convolution's forward — the same GEMM on
+// the NHWC activation and the packed forward panel — with the per-channel fp64 statistics of the following BatchNorm taken
+// from the accumulators, as conv_igemm_kernel's epilogue takes them.
+template <int NS, int BK, int EPI = 0>
 __global__ __launch_bounds__(SB_THREADS) void gemm_rows_bf16split_kernel(const SplitArgs p) {
   // LDS rows are BK bf16 wide, unpadded; the 16-byte chunks of a row are XOR-swizzled with the index of the 256-byte
   // group the row sits in, which makes both the 16-byte fragment reads (16 rows per LDS cycle, 64 banks) and the 8-byte
@@ -157,6 +163,45 @@ __global__ __launch_bounds__(SB_THREADS) void gemm_rows_bf16split_kernel(const S
   // K = 256 tile (the 46 layer3 GEMMs of a PSPNet-101 step).  Each wave therefore transposes block by block through a
   // private 32 x 36-float slab of the (now idle) staging LDS and stores 16-byte lanes: 4 stores per lane and block.
   // Same-wave LDS traffic is ordered, so no barrier is needed between a block's writes, its reads and the next block.
+  if constexpr (EPI == 1) {
+    if (p.stats) {
+      // lane = one column of block j, 32 of the wave's 64 rows in its registers: fp64 sums over them, the two lane halves
+      // combined by a shuffle, the four row-waves through LDS (the staging area is idle: the K loop ended on a barrier),
+      // then one atomic pair per column and workgroup into the slot replica of this row tile
+      double* red = reinterpret_cast<double*>(smem_raw);          // [4 (wm)][SB_BN][2]
+      const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            const double d = row < p.M ? (double)acc[i][j][e] : 0.0;
+            s1 += d;
+            s2 += d * d;
+          }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lhi == 0) {
+          red[(wm * SB_BN + wn * 64 + j * 32 + l31) * 2 + 0] = s1;
+          red[(wm * SB_BN + wn * 64 + j * 32 + l31) * 2 + 1] = s2;
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * SB_BN) {
+        const int col = tid >> 1, which = tid & 1;
+        if (n0 + col < p.Nout) {
+          double v = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v += red[(r * SB_BN + col) * 2 + which];
+          atomic_add_f64(&p.stats[(size_t)(tm % p.nslot) * 2 * p.Nout + (size_t)which * p.Nout + n0 + col], v);
+        }
+      }
+      __syncthreads();       // the slabs below reuse the same LDS
+    }
+  }
   const bool wide = EPI_WIDE && (p.ldc & 3) == 0 && (p.Nout & 3) == 0 && ((((size_t)C) & 15) == 0);
   if (wide) {
     float* slab = reinterpret_cast<float*>(smem_raw) + wave * (32 * SLAB_LD);
@@ -202,6 +247,7 @@ extern "C" int semseg_gemm_rows_batched_bf16split(const float* a, int lda, long 
   if ((nsplit != 2 && nsplit != 3) || (bk != 16 && bk != 32) || K % bk != 0 || (lda & 3) || (K & 3)) return SEMSEG_EINVAL;
   if (nsplit == 3 && bk != 16) return SEMSEG_EINVAL;      // three pieces at BK 32 would not leave two workgroups per CU
   SplitArgs p;
+  p.stats = nullptr; p.nslot = 1;
   p.a = a; p.bt = bt; p.c = c;
   p.a_bs = a_bs; p.bt_bs = bt_bs; p.c_bs = c_bs;
   p.lda = lda; p.ldc = ldc; p.M = M; p.K = K; p.Nout = Nout;
@@ -211,5 +257,20 @@ extern "C" int semseg_gemm_rows_batched_bf16split(const float* a, int lda, long 
   if (nsplit == 2 && bk == 32) gemm_rows_bf16split_kernel<2, 32><<<p.total, SB_THREADS, 0, stream>>>(p);
   else if (nsplit == 2) gemm_rows_bf16split_kernel<2, 16><<<p.total, SB_THREADS, 0, stream>>>(p);
   else gemm_rows_bf16split_kernel<3, 16><<<p.total, SB_THREADS, 0, stream>>>(p);
+  return semseg_launch_status();
+}
+
+// tile code 2128 of semseg_conv_fwd (conv_igemm.hip): y[M][Co] = x[M][Ci] * w_fwd[Co_pad][Ci]^T + statistics, on the kernel above
+int semseg_split_gemm_conv1x1_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int M, int Ci, int Co,
+                                  double* stats, int nslot, hipStream_t stream) {
+  SplitArgs p;
+  p.a = x; p.bt = w_fwd; p.c = y;
+  p.a_bs = p.bt_bs = p.c_bs = 0;
+  p.lda = ldx; p.ldc = ldy; p.M = M; p.K = Ci; p.Nout = Co;
+  p.tiles_m = (M + SB_BM - 1) / SB_BM;
+  p.tiles_n = (Co + SB_BN - 1) / SB_BN;
+  p.total = p.tiles_m * p.tiles_n;
+  p.stats = stats; p.nslot = nslot > 0 ? nslot : 1;
+  gemm_rows_bf16split_kernel<3, 16, 1><<<p.total, SB_THREADS, 0, stream>>>(p);
   return semseg_launch_status();
 }

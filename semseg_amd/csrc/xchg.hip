@@ -15,7 +15,7 @@
 // raises it after it has finished s - 1), so two slot sets are enough and nothing is ever reset.
 // Ordering: data stores, then __threadfence_system() in every storing thread, then a workgroup barrier, then the flag
 // stores (system-scope release); the consumer polls its flags with system-scope acquire loads (s_sleep between polls),
-// then reads the slots with system-scope loads.  Every spin is bounded: after ~1 s the kernel gives up, sets *err and
+// then reads the slots with system-scope loads.  Every spin is bounded: after 20 s the kernel gives up, sets *err and
 // finishes with whatever it has — the host raises (SyncExchange.check()).
 //
 // STATUS (round 4): exercised with two processes on ONE GPU (tests/test_dist_gpu.py, both ranks' buffers in the same HBM,
@@ -69,10 +69,14 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(const XchgArgs p) 
   __syncthreads();
   if (tid < W) {
     const unsigned long long* f = flags_of(p.peer[p.rank], W, par) + tid;
-    long long spins = 0;
+    // 100 MHz constant clock.  The bound has to cover honest skew between the ranks' HOSTS (a peer's exchange kernel is only
+    // launched when its python thread gets there: first-use code-object loads, a rank whose process was scheduled late — a
+    // 1 s bound fired once in the two-processes-on-one-GPU test), so it is 20 s; an exchange that already failed in this
+    // process makes the following ones give up at once instead of waiting 20 s each.
+    const unsigned long long t0 = wall_clock64(), limit = *p.err ? 0ull : 2000000000ull;
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.seq) {
       __builtin_amdgcn_s_sleep(16);
-      if (++spins > 4000000ll) {      // ~1 s: a peer never arrived (not co-resident, crashed, different call sequence)
+      if (wall_clock64() - t0 > limit) {      // a peer never arrived (crashed, different call sequence, not co-resident)
         bad = 1;
         break;
       }

@@ -533,7 +533,9 @@ class Engine:
         rs = cl.R * cl.S if cl.R * cl.S in (1, 9) else 0
         ar = cl.arith if rs else ops.ARITH_F32       # the generic tap walk has no split instance
         tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld, ar)
-        ev = self._t0("conv_igemm_kernel<%d,%d,false,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)), 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
+        fam = ("gemm_rows_bf16split_kernel<3,16,1> (bf16x3, 1x1 conv + statistics)" if tile == ops.TILE_SPLIT_GEMM else
+               "conv_igemm_kernel<%d,%d,false,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)))
+        ev = self._t0(fam, 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
         if fold is not None:
             sc, sh, relu, res = fold
             ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,

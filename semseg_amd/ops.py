@@ -86,6 +86,7 @@ import os as _os
 
 TILE_TABLE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tile_table.json")
 TILE_TUNE = _os.environ.get("SEMSEG_TILE_TUNE", "0") == "1"
+_FORCE_SPLIT_GEMM = _os.environ.get("SEMSEG_FORCE_SPLIT_GEMM", "0") == "1"    # measurement: every eligible shape on tile code 2128
 
 
 def tile_key(kind, N, H, W, Ci, Co, R, S, stride, pad, dil):
@@ -109,13 +110,24 @@ def _load_tables():
         for k, v in load_tile_table(path).items():
             f = k.split("|")
             ncols = int(f[5]) if f[0] == "fwd" else int(f[4])      # fwd: Co columns, dgrad: Ci columns
-            if v not in TILE_CODES or (ncols < 128 and v % 1000 > 64):
+            if v not in TILE_CODES + (TILE_SPLIT_GEMM,) or (ncols < 128 and v % 1000 > 64):
+                continue
+            if v == TILE_SPLIT_GEMM and not (k.endswith("|sp") and _split_gemm_eligible(k)):
                 continue
             out[k] = v
     return out
 
 
+def _split_gemm_eligible(key):
+    """Forward of a 1x1, stride-1, unpadded conv with whole 128-column panels: the shapes tile code 2128 exists for."""
+    f = key.split("|")
+    return f[0] == "fwd" and f[6:10] == ["1", "1", "1", "0"] and int(f[5]) % 128 == 0
+
+
 TILE_CODES = (128, 64, 1128, 1064)   # 128x128, 128x64, 64x128, 64x64 (rows x columns; include/semseg_hip.h)
+# 2128: semseg_conv_fwd runs the 256 x 128 bf16x3 GEMM kernel (gemm_bf16split.hip, the Winograd path's GEMM) with the statistics
+# epilogue instead of the implicit-GEMM kernel — bf16x3 table only, eligible shapes only (the library falls back to 128)
+TILE_SPLIT_GEMM = 2128
 TILE_TIMES = {}   # key -> {tile code: ms per launch}, filled in tuning mode only
 # tile shapes measured with the SEMSEG_ARITH_BF16X3 instances of the kernels: keys suffixed "|sp"
 TILE_TABLE_SP_PATH = _os.environ.get("SEMSEG_TILE_TABLE_SP") or TILE_TABLE_PATH.replace("tile_table.json", "tile_table_sp.json")
@@ -128,6 +140,10 @@ def _tuned_tile(key, dflt, device, out_floats, launch, arith=ARITH_F32):
     codes = TILE_CODES if dflt == 128 else (64, 1064)
     if arith == ARITH_BF16X3:
         key = key + "|sp"
+        if dflt == 128 and _split_gemm_eligible(key):
+            codes = codes + (TILE_SPLIT_GEMM,)
+            if _FORCE_SPLIT_GEMM:
+                return TILE_SPLIT_GEMM
     t = TILE_CHOICE.get(key)
     if t is not None:
         return t if (dflt == 128 or t % 1000 == 64) else dflt
@@ -169,11 +185,12 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
     Ho = conv_out(H, pk.R, stride, pad, dil)
     Wo = conv_out(W, pk.S, stride, pad, dil)
     ldt = roundup(pk.Co, 4)
+    tstats = torch.zeros(NSLOT * 2 * pk.Co, dtype=torch.float64, device=x.device) if TILE_TUNE else None   # timed with statistics
     tile = _tuned_tile(tile_key("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil), pk.tile_fwd, x.device,
                        N * Ho * Wo * ldt,
                        lambda t, out: lib.semseg_conv_fwd(
                            _p(x), ldx, _p(pk.w_fwd), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
-                           pad, dil, None, None, 0, None, 0, None, 1, t, arith, *_scr(scratch), _stream()), arith)
+                           pad, dil, None, None, 0, None, 0, _p(tstats), NSLOT, t, arith, *_scr(scratch), _stream()), arith)
     _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
                             pk.R, pk.S, stride, pad, dil, _p(bias), _p(scale), int(relu), _p(add), ldadd,
                             _p(stats), nslot, tile, arith, *_scr(scratch), _stream()), "conv_fwd")
@@ -184,6 +201,8 @@ def chosen_tile(kind, pk, N, H, W, stride, pad, dil, ld_in, ld_out, arith=ARITH_
     """Tile width the (already measured) shape runs with; kind "fwd" | "dgrad".  For kernel-family labels."""
     dflt = pk.tile_fwd if kind == "fwd" else pk.tile_dgrad
     key = tile_key(kind, N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil) + ("|sp" if arith == ARITH_BF16X3 else "")
+    if _FORCE_SPLIT_GEMM and dflt == 128 and arith == ARITH_BF16X3 and _split_gemm_eligible(key):
+        return TILE_SPLIT_GEMM
     t = TILE_CHOICE.get(key, dflt)
     return t if (dflt == 128 or t % 1000 == 64) else dflt
 

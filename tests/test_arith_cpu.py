@@ -68,13 +68,38 @@ def test_table_entry_wider_than_the_packed_panel_is_not_used(monkeypatch):
     assert ops._tuned_tile(key, 64, None, 0, never) == 1064
 
 
+def test_split_gemm_tile_code_is_only_taken_for_eligible_shapes(monkeypatch):
+    """Tile code 2128: 1x1, stride 1, no padding, whole 128-column panels, forward, bf16x3 table.  A table entry naming it for
+    anything else is dropped at load time; the exact-fp32 lookup never returns it."""
+    from semseg_amd import ops
+    ok = ops.tile_key("fwd", 16, 60, 60, 1024, 256, 1, 1, 1, 0, 1) + "|sp"
+    assert ops._split_gemm_eligible(ok)
+    for bad in (ops.tile_key("dgrad", 16, 60, 60, 1024, 256, 1, 1, 1, 0, 1) + "|sp",      # data gradient
+                ops.tile_key("fwd", 16, 60, 60, 1024, 256, 3, 3, 1, 1, 1) + "|sp",        # 3x3
+                ops.tile_key("fwd", 16, 119, 119, 256, 512, 1, 1, 2, 0, 1) + "|sp",       # strided
+                ops.tile_key("fwd", 16, 60, 60, 512, 150, 1, 1, 1, 0, 1) + "|sp"):        # 150 columns
+        assert not ops._split_gemm_eligible(bad)
+    import json as _json, tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        _json.dump({"tiles": {ok: 2128, ok.replace("fwd", "dgrad"): 2128}}, f)
+    monkeypatch.setattr(ops, "TILE_TABLE_SP_PATH", f.name)
+    t = ops._load_tables()
+    assert t.get(ok) == 2128 and ok.replace("fwd", "dgrad") not in t
+    never = lambda *a: (_ for _ in ()).throw(AssertionError("no launch expected"))
+    monkeypatch.setitem(ops.TILE_CHOICE, ok, 2128)
+    assert ops._tuned_tile(ok[:-3], 128, None, 0, never, ops.ARITH_BF16X3) == 2128
+    assert ops._tuned_tile(ok[:-3], 128, None, 0, never, ops.ARITH_F32) in ops.TILE_CODES
+
+
 def test_committed_tile_tables_are_well_formed():
     from semseg_amd import ops
     for path, sp in ((ops.TILE_TABLE_PATH, False), (ops.TILE_TABLE_SP_PATH, True)):
         assert os.path.exists(path), path
         tiles = json.load(open(path))["tiles"]
         assert tiles and all(k.endswith("|sp") == sp for k in tiles)
-        assert all(int(v) in ops.TILE_CODES for v in tiles.values())
+        # code 2128 (the 256 x 128 bf16x3 GEMM kernel for 1x1 forward convs) only in the bf16x3 table, only for eligible shapes
+        assert all(int(v) in ops.TILE_CODES or (sp and int(v) == ops.TILE_SPLIT_GEMM and ops._split_gemm_eligible(k))
+                   for k, v in tiles.items())
         assert all(k.split("|")[0] in ("fwd", "dgrad") for k in tiles)
         for k, v in tiles.items():          # column width never exceeds the padding of the layer's packed panels
             f = k.split("|")

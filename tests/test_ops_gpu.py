@@ -101,6 +101,47 @@ def test_conv_dgrad_fused_bn_backward_reduce(case, mask, report):
     assert e_g < 2e-5 and max(errs) < 2e-5
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, Ci, Co
+    (2, 30, 30, 256, 1024),     # layer3 conv3 at a small batch; M = 1800: a partial 256-row tile at the end
+    (3, 15, 15, 1024, 256),     # layer3 conv1: K = 1024
+    (1, 17, 19, 64, 128),       # one column tile, M = 323
+    (2, 20, 20, 512, 384),      # three column tiles
+])
+def test_conv_fwd_1x1_on_the_split_gemm_kernel(case, report, monkeypatch):
+    """Tile code 2128 of semseg_conv_fwd: the forward of a 1x1 stride-1 conv under SEMSEG_ARITH_BF16X3 on the 256 x 128 GEMM
+    kernel of gemm_bf16split.hip with the fp64 statistics epilogue; operands in wider buffers, replicated statistics slots.
+    Same bounds as the implicit-GEMM kernel; an ineligible call (bias in the epilogue) silently takes the 128 x 128 tile."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) * (1.0 / Ci ** 0.5)
+    y64 = F.conv2d(x.double(), w.double())
+    pk = ops.PackedConv(Co, Ci, 1, 1, DEV)
+    pk.pack(w.to(DEV))
+    ldx, ldy = Ci + 64, Co + 128
+    xb = torch.randn(N, H, W, ldx, device=DEV)
+    xb[..., 32:32 + Ci] = nhwc(x).to(DEV)
+    NS = ops.NSLOT
+    monkeypatch.setattr(ops, "_FORCE_SPLIT_GEMM", True)
+    assert ops.chosen_tile("fwd", pk, N, H, W, 1, 0, 1, ldx, ldy, ops.ARITH_BF16X3) == ops.TILE_SPLIT_GEMM
+    yb = torch.full((N, H, W, ldy), float("nan"), device=DEV)
+    st = torch.zeros(NS * 2 * Co, dtype=torch.float64, device=DEV)
+    ops.conv_fwd(xb[..., 32:], ldx, pk, yb, ldy, N, H, W, 1, 0, 1, stats=st, nslot=NS, arith=ops.ARITH_BF16X3)
+    assert torch.isnan(yb[..., Co:]).all()
+    e_f = relerr(nchw(yb[..., :Co]), y64)
+    tot = st.view(NS, 2, Co).sum(0).cpu()
+    e_s = max(relerr(tot[0], y64.sum((0, 2, 3))), relerr(tot[1], (y64 * y64).sum((0, 2, 3))))
+    # with a bias the same call falls back to the implicit-GEMM kernel
+    bias = torch.randn(Co, generator=g)
+    yb2 = torch.empty(N, H, W, Co, device=DEV)
+    ops.conv_fwd(xb[..., 32:], ldx, pk, yb2, Co, N, H, W, 1, 0, 1, bias=bias.to(DEV), arith=ops.ARITH_BF16X3)
+    e_b = relerr(nchw(yb2), y64 + bias.double().view(1, -1, 1, 1))
+    report("1x1 forward on the 256x128 bf16x3 GEMM kernel %s: y %.2e stats %.2e (fallback with bias %.2e)" % (case, e_f, e_s, e_b))
+    assert max(e_f, e_b) < 2e-5 and e_s < 1e-5
+
+
 WGRAD_BIG_CASES = [
     # N, H, W, Ci, Co, k, stride, pad, dil  (Ci % 128 == 0, Co >= 128: the 128 x 128 weight-gradient tile)
     (2, 13, 13, 128, 128, 3, 1, 2, 2),     # "same" dilated 3x3: linear gather with border taps out of range
