@@ -50,7 +50,7 @@ def main():
     grp = {}
     ti = 0
     for family, flops, s, e in kt.rec:
-        if family.startswith("conv_igemm_kernel") and ",true," in family:
+        if (family.startswith("conv_igemm_kernel") and ",true," in family) or "<3,16,2>" in family:
             family = family.split("(")[0] + " " + tags[ti]
             ti += 1
         d = grp.setdefault((family, flops), [0, 0.0])

@@ -1009,7 +1009,8 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 // tile code of the C ABI: 128 / 64 = 128-row tiles, that many output columns; 1128 / 1064 = 64-row tiles (2 waves), for
 // launches whose 128-row grid would not fill the chip (small per-GPU batch) — 4x the tiles of a 128 x 128 grid without
 // splitting K, so no partial slabs and no separate epilogue pass
-// 2128: the 256 x 128 bf16x3 GEMM kernel of gemm_bf16split.hip for eligible 1x1 forward convs (semseg_conv_fwd), else 128
+// 2128: the 256 x 128 bf16x3 GEMM kernel of gemm_bf16split.hip for eligible 1x1 convs (forward: semseg_conv_fwd, data gradient:
+// dgrad_impl), else 128
 static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064 || t == 1128 || t == 2128; }
 
 
@@ -1180,9 +1181,28 @@ static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx
                       int pad, int dil, const float* add, int ldadd, int tile_n, int arith, const ConvArgs* bnr,
                       float* scratch, size_t scratch_floats, hipStream_t stream) {
   if (!dy || !w_dgrad || !dx || (lddy & 3) || !tile_code_ok(tile_n) || !arith_ok(arith)) return SEMSEG_EINVAL;
-  if (tile_n == 2128) tile_n = 128;
   const int Kc = (Co + 31) / 32 * 32;
   if (lddy < Kc) return SEMSEG_EINVAL;
+  if (tile_n == 2128) {
+    // the 256 x 128 bf16x3 GEMM kernel (gemm_bf16split.hip): 1x1, stride 1, no padding, whole 128-column panels, at most one
+    // fused BatchNorm layer, and a reduction of at most 1024: that kernel accumulates ONE fp32 chain (no registers for the
+    // second accumulator set this file flushes chains longer than 576 into).  Measured in situ (PSPNet-101 473^2, every
+    // eligible layer forced onto it, K up to 2048): rms error 1.7 x the CPU-fp32 recompute's at worst (K = 2048), 2.6 x in the
+    // maximum, against 1.2 x / 1.6 x with flushing — inside the 3 x / 5 x criterion, and K <= 1024 keeps it to the layers
+    // where the kernel pays (layer3's conv3: 215 -> 178 us).  Anything else runs the 128 x 128 implicit-GEMM tile.
+    const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W;
+    const bool al = (lddx & 3) == 0 && lddx >= Ci && ((size_t)dx & 15) == 0 && (!add || ((ldadd & 3) == 0 && ((size_t)add & 15) == 0));
+    if (arith == SEMSEG_ARITH_BF16X3 && plain && al && Ci % 128 == 0 && Kc <= 1024 && (!bnr || bnr->bnr_n == 1)) {
+      const bool on = bnr != nullptr;
+      return semseg_split_gemm_conv1x1_dgrad(dy, lddy, w_dgrad, dx, lddx, N * H * W, Kc, Ci, add, ldadd,
+                                             on ? bnr->bnr_mask : nullptr, on ? bnr->bnr_ldm : 0,
+                                             on ? bnr->bnr_bits : nullptr, on ? bnr->bnr_ldb : 0,
+                                             on ? bnr->bnr_y[0] : nullptr, on ? bnr->bnr_ldy[0] : 0,
+                                             on ? bnr->bnr_mean[0] : nullptr, on ? bnr->bnr_invstd[0] : nullptr,
+                                             on ? bnr->bnr_sums[0] : nullptr, on ? bnr->stats_nslot : 1, stream);
+    }
+    tile_n = 128;
+  }
   ConvArgs a;
   a.x = dy; a.w = w_dgrad; a.y = dx; a.bias = nullptr; a.scale = nullptr; a.relu = 0; a.add = add; a.stats = nullptr;
   a.ldx = lddy; a.ldy = lddx; a.ldadd = ldadd;

@@ -14,6 +14,8 @@
 // time: global -> registers (prefetched one stage ahead) -> split -> LDS [rows][BK] bf16 per piece (chunk-swizzled) ->
 // fragments.  Measured and set aside in round 3 (git history, commit 9e79bfe: csrc/experiments/gemm_bf16split_256sq.inc): a
 // 256 x 256 tile with a deeper pipeline ran the six-product form in the same time.
+#include <cstring>
+
 #include "common.h"
 #include "gemm_bf16split.h"
 #include "../../include/semseg_hip.h"
@@ -34,7 +36,64 @@ struct SplitArgs {
   int lda, ldc, M, K, Nout, tiles_m, tiles_n, total;
   double* stats;        // EPI 1: [nslot][2 * Nout] fp64 {sum, sum of squares} per column of C (semseg_conv_fwd's statistics)
   int nslot;
+  // EPI 2 (data gradient of a 1x1 conv): C = product (+ add); with bnr_n = 1 the fused BatchNorm-backward reduction of
+  // semseg_conv_dgrad_bnreduce: C = g = (product (+ add)) * mask, sums[slot][2 * Nout] += {sum g, sum g * (ybn - mean) * invstd}
+  const float* add; int ldadd;
+  int bnr_n;
+  const float* mask; int ldm;          // post-ReLU activation (null: no ReLU or bits given)
+  const unsigned* bits; int ldb;       // the same mask as bits (semseg_bn_apply's relu_bits)
+  const float* ybn; int ldybn;
+  const float* mean; const float* invstd;
+  double* sums;
 };
+
+// Rows rr, rr + 8, rr + 16, rr + 24 of one 32 x 32 block (already transposed into the wave's slab) through the fused
+// reduction, two rows' operands in flight at a time (the kernel has no registers to spare: 128 VGPRs = two workgroups per CU).
+// MASK: 0 none, 1 post-ReLU activation, 2 bits.  bs[0..3] += g, bs[4..7] += g * xhat (fp32 over the lane's 8 rows of a column
+// block, fp64 above that — the accumulation scheme of conv_igemm.hip's bnr_rows).
+template <bool HAS_ADD, int MASK>
+__device__ __forceinline__ void split_bnr_block(const SplitArgs& p, const float* slab, int slab_ld, float* C, int rowbase,
+                                                int colb, bool colok, int lane, const f32x4 bmu, const f32x4 bis,
+                                                float (&bs)[8]) {
+  const int rr = lane >> 3, c4 = (lane & 7) * 4;
+  const int cc = colok ? colb : 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 y0[2], dd[HAS_ADD ? 2 : 1], aa[MASK == 1 ? 2 : 1];
+    unsigned wb[MASK == 2 ? 2 : 1];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = rowbase + rr + 8 * (2 * h + q);
+      const size_t mm = (size_t)(row < p.M ? row : p.M - 1);
+      y0[q] = *reinterpret_cast<const f32x4*>(p.ybn + mm * p.ldybn + cc);
+      if constexpr (HAS_ADD) dd[q] = *reinterpret_cast<const f32x4*>(p.add + mm * p.ldadd + cc);
+      if constexpr (MASK == 1) aa[q] = *reinterpret_cast<const f32x4*>(p.mask + mm * p.ldm + cc);
+      if constexpr (MASK == 2) wb[q] = p.bits[mm * p.ldb + (cc >> 5)];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = rr + 8 * (2 * h + q);
+      const int row = rowbase + r;
+      const bool ok = row < p.M && colok;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&slab[r * slab_ld + c4]);
+      if constexpr (HAS_ADD) v += dd[q];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bool keep = true;
+        if constexpr (MASK == 1) keep = aa[q][k] > 0.f;
+        if constexpr (MASK == 2) keep = (wb[q] >> ((cc & 31) + k)) & 1u;
+        v[k] = (keep && ok) ? v[k] : 0.f;
+      }
+      const f32x4 xh = (y0[q] - bmu) * bis;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bs[k] += v[k];
+        bs[4 + k] = fmaf(v[k], xh[k], bs[4 + k]);
+      }
+      if (ok) *reinterpret_cast<f32x4*>(&C[(size_t)row * p.ldc + colb]) = v;
+    }
+  }
+}
 
 // x -> NS bf16 pieces (round to nearest even at every level; the remainders are exact in fp32)
 template <int NS>
@@ -51,7 +110,7 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[NS]) {
 // the NHWC activation and the packed forward panel — with the per-channel fp64 statistics of the following BatchNorm taken
 // from the accumulators, as conv_igemm_kernel's epilogue takes them.
 template <int NS, int BK, int EPI = 0>
-__global__ __launch_bounds__(SB_THREADS) void gemm_rows_bf16split_kernel(const SplitArgs p) {
+__global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(const SplitArgs p) {
   // LDS rows are BK bf16 wide, unpadded; the 16-byte chunks of a row are XOR-swizzled with the index of the 256-byte
   // group the row sits in, which makes both the 16-byte fragment reads (16 rows per LDS cycle, 64 banks) and the 8-byte
   // staging stores (128 contiguous bytes per 16 lanes, 32 banks) conflict-free.  (The first version padded rows by 16
@@ -66,7 +125,9 @@ __global__ __launch_bounds__(SB_THREADS) void gemm_rows_bf16split_kernel(const S
   constexpr int SLAB_LD = 36;                                           // floats per slab row (conflict-free ds_read_b128)
   constexpr int STAGE_BYTES = NS * (SB_BM + SB_BN) * BK * 2;
   constexpr int SLAB_BYTES = (SB_THREADS / 64) * 32 * SLAB_LD * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES];
+  constexpr int RED2_BYTES = EPI == 2 ? 4 * SB_BN * 2 * 8 : 0;          // fp64 column sums of the fused reduction: [4 (wm)][SB_BN][2]
+  constexpr int EPI_BYTES = SLAB_BYTES + RED2_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
   __bf16 (*sA)[SB_BM * BK] = reinterpret_cast<__bf16 (*)[SB_BM * BK]>(smem_raw);
   __bf16 (*sB)[SB_BN * BK] = reinterpret_cast<__bf16 (*)[SB_BN * BK]>(smem_raw + NS * SB_BM * BK * 2);
 
@@ -202,6 +263,78 @@ __global__ __launch_bounds__(SB_THREADS) void gemm_rows_bf16split_kernel(const S
       __syncthreads();       // the slabs below reuse the same LDS
     }
   }
+  if constexpr (EPI == 2) {
+    // the launcher guarantees the 16-byte path: ldc % 4 == 0, Nout % 128 == 0, aligned bases
+    float* slab = reinterpret_cast<float*>(smem_raw) + wave * (32 * SLAB_LD);
+    double* red2 = reinterpret_cast<double*>(smem_raw + SLAB_BYTES);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+    const bool bnr = p.bnr_n > 0;
+    const int mode = p.bits ? 2 : (p.mask ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int colb = n0 + wn * 64 + j * 32 + c4;
+      const bool colok = colb < p.Nout;
+      f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bis = {0.f, 0.f, 0.f, 0.f};
+      if (bnr && colok) {
+        bmu = *reinterpret_cast<const f32x4*>(p.mean + colb);
+        bis = *reinterpret_cast<const f32x4*>(p.invstd + colb);
+      }
+      float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * lhi) * SLAB_LD + l31] = acc[i][j][e];
+        const int rowbase = m0 + wm * 64 + i * 32;
+        if (bnr) {
+#define SPLIT_BNR(A_, M_) split_bnr_block<A_, M_>(p, slab, SLAB_LD, C, rowbase, colb, colok, lane, bmu, bis, bs)
+          if (p.add) {
+            if (mode == 2) SPLIT_BNR(true, 2); else if (mode == 1) SPLIT_BNR(true, 1); else SPLIT_BNR(true, 0);
+          } else {
+            if (mode == 2) SPLIT_BNR(false, 2); else if (mode == 1) SPLIT_BNR(false, 1); else SPLIT_BNR(false, 0);
+          }
+#undef SPLIT_BNR
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int r = rr + 8 * t;
+            const int row = rowbase + r;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&slab[r * SLAB_LD + c4]);
+            if (row < p.M && colok) {
+              if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + (size_t)row * p.ldadd + colb);
+              *reinterpret_cast<f32x4*>(&C[(size_t)row * p.ldc + colb]) = v;
+            }
+          }
+        }
+      }
+      if (bnr) {
+        // lanes with equal (lane & 7) hold the same 4 columns for different rows: fold them in fp64, lanes 0-7 keep the totals
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          double t = (double)bs[k];
+          t += __shfl_xor(t, 8);
+          t += __shfl_xor(t, 16);
+          t += __shfl_xor(t, 32);
+          if (lane < 8) red2[((wm * SB_BN) + wn * 64 + j * 32 + lane * 4 + (k & 3)) * 2 + (k >> 2)] = t;
+        }
+      }
+    }
+    if (bnr) {
+      __syncthreads();
+      if (tid < SB_BN && n0 + tid < p.Nout) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1 += red2[(r * SB_BN + tid) * 2 + 0];
+          s2 += red2[(r * SB_BN + tid) * 2 + 1];
+        }
+        double* st = p.sums + (size_t)(tm % p.nslot) * 2 * p.Nout;
+        atomic_add_f64(&st[n0 + tid], s1);
+        atomic_add_f64(&st[p.Nout + n0 + tid], s2);
+      }
+    }
+    return;
+  }
   const bool wide = EPI_WIDE && (p.ldc & 3) == 0 && (p.Nout & 3) == 0 && ((((size_t)C) & 15) == 0);
   if (wide) {
     float* slab = reinterpret_cast<float*>(smem_raw) + wave * (32 * SLAB_LD);
@@ -247,6 +380,7 @@ extern "C" int semseg_gemm_rows_batched_bf16split(const float* a, int lda, long 
   if ((nsplit != 2 && nsplit != 3) || (bk != 16 && bk != 32) || K % bk != 0 || (lda & 3) || (K & 3)) return SEMSEG_EINVAL;
   if (nsplit == 3 && bk != 16) return SEMSEG_EINVAL;      // three pieces at BK 32 would not leave two workgroups per CU
   SplitArgs p;
+  std::memset(&p, 0, sizeof(p));
   p.stats = nullptr; p.nslot = 1;
   p.a = a; p.bt = bt; p.c = c;
   p.a_bs = a_bs; p.bt_bs = bt_bs; p.c_bs = c_bs;
@@ -264,6 +398,7 @@ extern "C" int semseg_gemm_rows_batched_bf16split(const float* a, int lda, long 
 int semseg_split_gemm_conv1x1_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int M, int Ci, int Co,
                                   double* stats, int nslot, hipStream_t stream) {
   SplitArgs p;
+  std::memset(&p, 0, sizeof(p));
   p.a = x; p.bt = w_fwd; p.c = y;
   p.a_bs = p.bt_bs = p.c_bs = 0;
   p.lda = ldx; p.ldc = ldy; p.M = M; p.K = Ci; p.Nout = Co;
@@ -272,5 +407,27 @@ int semseg_split_gemm_conv1x1_fwd(const float* x, int ldx, const float* w_fwd, f
   p.total = p.tiles_m * p.tiles_n;
   p.stats = stats; p.nslot = nslot > 0 ? nslot : 1;
   gemm_rows_bf16split_kernel<3, 16, 1><<<p.total, SB_THREADS, 0, stream>>>(p);
+  return semseg_launch_status();
+}
+
+// tile code 2128 of semseg_conv_dgrad / semseg_conv_dgrad_bnreduce: dx[M][Ci] = dy[M][Kc] * w_dgrad[Ci_pad][Kc]^T (+ add), with
+// the fused BatchNorm-backward reduction of ONE layer when ybn is given
+int semseg_split_gemm_conv1x1_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int M, int Kc, int Ci,
+                                    const float* add, int ldadd, const float* act, int ldact, const unsigned* relu_bits,
+                                    int ldbits, const float* ybn, int ldybn, const float* mean, const float* invstd,
+                                    double* sums, int nslot, hipStream_t stream) {
+  SplitArgs p;
+  std::memset(&p, 0, sizeof(p));
+  p.a = dy; p.bt = w_dgrad; p.c = dx;
+  p.lda = lddy; p.ldc = lddx; p.M = M; p.K = Kc; p.Nout = Ci;
+  p.tiles_m = (M + SB_BM - 1) / SB_BM;
+  p.tiles_n = (Ci + SB_BN - 1) / SB_BN;
+  p.total = p.tiles_m * p.tiles_n;
+  p.nslot = nslot > 0 ? nslot : 1;
+  p.add = add; p.ldadd = ldadd;
+  p.bnr_n = ybn ? 1 : 0;
+  p.mask = relu_bits ? nullptr : act; p.ldm = ldact; p.bits = relu_bits; p.ldb = ldbits;
+  p.ybn = ybn; p.ldybn = ldybn; p.mean = mean; p.invstd = invstd; p.sums = sums;
+  gemm_rows_bf16split_kernel<3, 16, 2><<<p.total, SB_THREADS, 0, stream>>>(p);
   return semseg_launch_status();
 }

@@ -611,7 +611,10 @@ class Engine:
             rs = cl.R * cl.S if cl.R * cl.S in (1, 9) else 0
             ar = cl.arith if rs else ops.ARITH_F32
             tile = ops.chosen_tile("dgrad", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, y.ld, x.ld, ar)
-            ev = self._t0("conv_igemm_kernel<%d,%d,true,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)), flops)
+            fam = ("gemm_rows_bf16split_kernel<3,16,2> (bf16x3, 1x1 data gradient + fused reduction)"
+                   if tile == ops.TILE_SPLIT_GEMM and not (fuse and len(bs["bns"]) > 1) else
+                   "conv_igemm_kernel<%d,%d,true,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)))
+            ev = self._t0(fam, flops)
             if fuse:
                 ops.conv_dgrad_bnreduce(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
                                         x.data if bs["relu"] else None, x.ld,

@@ -69,22 +69,26 @@ def test_table_entry_wider_than_the_packed_panel_is_not_used(monkeypatch):
 
 
 def test_split_gemm_tile_code_is_only_taken_for_eligible_shapes(monkeypatch):
-    """Tile code 2128: 1x1, stride 1, no padding, whole 128-column panels, forward, bf16x3 table.  A table entry naming it for
-    anything else is dropped at load time; the exact-fp32 lookup never returns it."""
+    """Tile code 2128: 1x1, stride 1, no padding, whole 128-column panels, bf16x3 table; data gradients only with a reduction of
+    at most 1024.  A table entry naming it for anything else is dropped at load time; the exact-fp32 lookup never returns it."""
     from semseg_amd import ops
     ok = ops.tile_key("fwd", 16, 60, 60, 1024, 256, 1, 1, 1, 0, 1) + "|sp"
     assert ops._split_gemm_eligible(ok)
-    for bad in (ops.tile_key("dgrad", 16, 60, 60, 1024, 256, 1, 1, 1, 0, 1) + "|sp",      # data gradient
+    okd = ops.tile_key("dgrad", 16, 60, 60, 256, 1024, 1, 1, 1, 0, 1) + "|sp"     # 1024 -> 256 data gradient: K = 1024
+    assert ops._split_gemm_eligible(okd)
+    for bad in (ops.tile_key("dgrad", 16, 60, 60, 512, 2048, 1, 1, 1, 0, 1) + "|sp",      # data gradient over K = 2048 > 1024
+                ops.tile_key("dgrad", 16, 60, 60, 64, 256, 1, 1, 1, 0, 1) + "|sp",        # 64 input channels: no 128-column panel
                 ops.tile_key("fwd", 16, 60, 60, 1024, 256, 3, 3, 1, 1, 1) + "|sp",        # 3x3
                 ops.tile_key("fwd", 16, 119, 119, 256, 512, 1, 1, 2, 0, 1) + "|sp",       # strided
                 ops.tile_key("fwd", 16, 60, 60, 512, 150, 1, 1, 1, 0, 1) + "|sp"):        # 150 columns
         assert not ops._split_gemm_eligible(bad)
     import json as _json, tempfile
     with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
-        _json.dump({"tiles": {ok: 2128, ok.replace("fwd", "dgrad"): 2128}}, f)
+        badd = ops.tile_key("dgrad", 16, 60, 60, 512, 2048, 1, 1, 1, 0, 1) + "|sp"
+        _json.dump({"tiles": {ok: 2128, okd: 2128, badd: 2128}}, f)
     monkeypatch.setattr(ops, "TILE_TABLE_SP_PATH", f.name)
     t = ops._load_tables()
-    assert t.get(ok) == 2128 and ok.replace("fwd", "dgrad") not in t
+    assert t.get(ok) == 2128 and t.get(okd) == 2128 and badd not in t
     never = lambda *a: (_ for _ in ()).throw(AssertionError("no launch expected"))
     monkeypatch.setitem(ops.TILE_CHOICE, ok, 2128)
     assert ops._tuned_tile(ok[:-3], 128, None, 0, never, ops.ARITH_BF16X3) == 2128

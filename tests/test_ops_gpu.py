@@ -142,6 +142,60 @@ def test_conv_fwd_1x1_on_the_split_gemm_kernel(case, report, monkeypatch):
     assert max(e_f, e_b) < 2e-5 and e_s < 1e-5
 
 
+@pytest.mark.parametrize("mask", ["none", "act", "bits"])
+@pytest.mark.parametrize("case", [
+    # N, H, W, Ci, Co, with_add
+    (2, 30, 30, 1024, 256, True),      # layer3 conv1's data gradient at a small batch: K = 256, eight column tiles, M = 1800
+    (3, 15, 15, 256, 64, False),       # K = 64, M = 675
+    (1, 17, 19, 128, 512, True),       # K = 512, one column tile, M = 323 (a partial 256-row tile)
+    (2, 16, 16, 256, 1024, False),     # layer3 conv3's data gradient: K = 1024, the longest chain the kernel is given
+])
+def test_conv_dgrad_1x1_on_the_split_gemm_kernel(case, mask, report, monkeypatch):
+    """Tile code 2128 of semseg_conv_dgrad / semseg_conv_dgrad_bnreduce: the data gradient of a 1x1 stride-1 conv under
+    SEMSEG_ARITH_BF16X3 on the 256 x 128 GEMM kernel, plain (+ add) and with the fused BatchNorm-backward reduction of one layer
+    (mask none / activation / bits), against fp64; same bounds as the implicit-GEMM kernel."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co, with_add = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    w = torch.randn(Co, Ci, 1, 1, generator=g) * (1.0 / Co ** 0.5)
+    dy = torch.randn(N, Co, H, W, generator=g)
+    act = torch.relu(torch.randn(N, Ci, H, W, generator=g))
+    add = torch.randn(N, Ci, H, W, generator=g) if with_add else None
+    ybn = torch.randn(N, Ci, H, W, generator=g) * 2 + 0.5
+    mean, inv = torch.randn(Ci, generator=g), torch.rand(Ci, generator=g) + 0.5
+    dx64 = torch.nn.grad.conv2d_input((N, Ci, H, W), w.double(), dy.double())
+    if with_add:
+        dx64 = dx64 + add.double()
+    g64 = dx64 * (act > 0) if mask != "none" else dx64
+    pk = ops.PackedConv(Co, Ci, 1, 1, DEV)
+    pk.pack(w.to(DEV))
+    monkeypatch.setattr(ops, "_FORCE_SPLIT_GEMM", True)
+    assert ops.chosen_tile("dgrad", pk, N, H, W, 1, 0, 1, 0, 0, ops.ARITH_BF16X3) == ops.TILE_SPLIT_GEMM
+    ldy = ops.roundup(Co, 128)
+    dyb = torch.zeros(N, H, W, ldy, device=DEV)
+    dyb[..., :Co] = nhwc(dy).to(DEV)
+    NS = ops.NSLOT
+    # plain data gradient (+ add)
+    dxp = nhwc(add).to(DEV).contiguous() if with_add else torch.full((N, H, W, Ci), float("nan"), device=DEV)
+    ops.conv_dgrad(dyb, ldy, pk, dxp, Ci, N, H, W, 1, 0, 1, add=dxp if with_add else None, ldadd=Ci, arith=ops.ARITH_BF16X3)
+    e_p = relerr(nchw(dxp), dx64)
+    # fused reduction
+    dxb = nhwc(add).to(DEV).contiguous() if with_add else torch.full((N, H, W, Ci), float("nan"), device=DEV)
+    sums = torch.zeros(NS * 2 * Ci, dtype=torch.float64, device=DEV)
+    actb = nhwc(act).to(DEV).contiguous()
+    bns = [(nhwc(ybn).to(DEV).contiguous(), Ci, mean.to(DEV), inv.to(DEV), sums)]
+    ops.conv_dgrad_bnreduce(dyb, ldy, pk, dxb, Ci, N, H, W, 1, 0, 1, actb if mask == "act" else None, Ci, bns, NS,
+                            add=dxb if with_add else None, ldadd=Ci, arith=ops.ARITH_BF16X3,
+                            relu_bits=relu_bits(actb) if mask == "bits" else None)
+    e_g = relerr(nchw(dxb), g64)
+    tot = sums.view(NS, 2 * Ci).sum(0).cpu()
+    xh = (ybn.double() - mean.double().view(1, -1, 1, 1)) * inv.double().view(1, -1, 1, 1)
+    e_s = max(relerr(tot[:Ci], g64.sum((0, 2, 3))), relerr(tot[Ci:], (g64 * xh).sum((0, 2, 3))))
+    report("1x1 data gradient on the 256x128 bf16x3 GEMM kernel %s mask=%s: plain %.2e fused g %.2e sums %.2e"
+           % (case, mask, e_p, e_g, e_s))
+    assert max(e_p, e_g, e_s) < 2e-5
+
+
 WGRAD_BIG_CASES = [
     # N, H, W, Ci, Co, k, stride, pad, dil  (Ci % 128 == 0, Co >= 128: the 128 x 128 weight-gradient tile)
     (2, 13, 13, 128, 128, 3, 1, 2, 2),     # "same" dilated 3x3: linear gather with border taps out of range
