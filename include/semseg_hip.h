@@ -67,7 +67,9 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 /* y[M][Co] = [relu]( conv(x) (*scale) (+bias) (+add) ) — scale/bias/relu fold an eval-mode BatchNorm
  * (+ReLU, +residual) into the epilogue; stats (optional, [2*Co] fp64, caller-zeroed) receives the
  * per-channel sum and sum of squares of y for the following BatchNorm.  tile_n in {64, 128} = output columns of a 128-row tile, or 1064 / 1128 = 64-row tiles of 64 / 128 columns (launches whose
- * 128-row grid would not fill the chip);
+ * 128-row grid would not fill the chip), or 2128 = the 256 x 128 bf16x3 GEMM kernel with a statistics / fused-reduction epilogue (gemm_bf16split.hip) where the
+ * call is a plain row GEMM — SEMSEG_ARITH_BF16X3, 1x1, stride 1, no padding, nothing folded into the epilogue, whole 128-column panels; data gradients also: at most
+ * one fused BatchNorm layer and Co <= 1024 — and the 128 x 128 tile otherwise;
  * w_fwd must have Co_pad = roundup(Co, tile_n) rows.  Ci % 32 == 0.  scratch (optional) enables
  * split-K when the 128 x tile_n tile grid cannot fill the 256 CUs (small per-GPU batches). */
 int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
