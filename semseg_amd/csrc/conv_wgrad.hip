@@ -40,13 +40,16 @@ struct WgradArgs {
 // MODE 0: generic gather (any stride / padding).  MODE 1: 1x1, stride 1, pad 0 — the gathered row IS row m,
 // no decode, always valid.  MODE 2: stride 1 with Ho x Wo == Hin x Win ("same" 3x3, any dilation) — the
 // gathered row is m + tap offset (linear); the pixel is decoded only for the border test.
-// SP = 3 (SEMSEG_ARITH_BF16X3, include/semseg_hip.h), 128 x 128 only — each thread
+// SP = 3 (SEMSEG_ARITH_BF16X3, include/semseg_hip.h) — each thread
 // stages FOUR CONSECUTIVE pixels of its four channels, cuts them into three bf16 pieces and stores them pixel-contiguous
 // ([channel][32 pixels] planes, the layout the bf16 matrix-core instruction wants for a K-major operand), and the
-// product is formed from six v_mfma_f32_32x32x16_bf16 per 16 pixels.
+// product is formed from six v_mfma_f32_32x32x16_bf16 per 16 pixels.  128 x 128: every thread stages both operands;
+// 64 x 64 (the layers with 64 input or output channels, and every layer of a small per-GPU batch): a stage is half the
+// data, so waves 0-1 stage dy and waves 2-3 stage x (HALF below).
 template <int TM, int TN, int MODE, int SP = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
-  static_assert(SP == 0 || (TM == 128 && TN == 128), "split mode needs 4 float4 per thread and operand");
+  static_assert(SP == 0 || (TM == TN && (TM == 128 || TM == 64)), "split mode needs 4 float4 per staging thread and operand");
+  constexpr bool HALF = SP != 0 && TM == 64;
   WgradArgs p = pin;
   if (p.batch > 1) {
     const long long bz = blockIdx.y;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
   }
   constexpr int MREP = TM / 64, NREP = TN / 64;
   constexpr int YV = TM / 4, XV = TN / 4;          // float4 per k-row
-  constexpr int Y_PER = 32 * YV / 256, X_PER = 32 * XV / 256;
+  constexpr int Y_PER = HALF ? 4 : 32 * YV / 256, X_PER = HALF ? 4 : 32 * XV / 256;
   constexpr int YROWS = 256 / YV, XROWS = 256 / XV;  // k-rows covered per pass
   __shared__ __attribute__((aligned(16))) float smem[SP ? SP * 16 * (TM + TN) : 32 * (TM + TN)];
   float* Ys = smem;            // [32][TM]
@@ -83,8 +86,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
 
   // SP: the pixel group (4 consecutive pixels) is the fastest thread index, so that the 8 lanes of one channel quad
   // fill one 64-byte LDS row per store
-  const int yc = SP ? tid >> 3 : tid % YV, yr = SP ? tid & 7 : tid / YV;
-  const int xc = SP ? tid >> 3 : tid % XV, xr = SP ? tid & 7 : tid / XV;
+  const int st = HALF ? (tid & 127) : tid;          // index among the threads staging one operand
+  const bool stage_y = !HALF || tid < 128, stage_x = !HALF || tid >= 128;   // wave-uniform
+  const int yc = SP ? st >> 3 : tid % YV, yr = SP ? st & 7 : tid / YV;
+  const int xc = SP ? st >> 3 : tid % XV, xr = SP ? st & 7 : tid / XV;
   const int hw = p.Ho * p.Wo;
 
   f32x4 ry[Y_PER], rx[X_PER];
@@ -97,12 +102,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
   // deep register prefetch (occupancy 3 -> 2, -5.6 %), XCD-aware block order (neutral in time), K-contiguous
   // LDS with ds_read_b128 fragments (-1 %).
   auto prefetch_into = [&](int kb, f32x4 (&ry)[Y_PER], f32x4 (&rx)[X_PER]) {
+    if (stage_y)
 #pragma unroll
     for (int i = 0; i < Y_PER; ++i) {
       const int m = SP ? kb + yr * Y_PER + i : kb + yr + i * YROWS;
       const float* src = m < kend ? p.dy + (size_t)m * p.lddy + co0 + yc * 4 : g_zero_line;
       ry[i] = *reinterpret_cast<const f32x4*>(src);
     }
+    if (stage_x)
 #pragma unroll
     for (int i = 0; i < X_PER; ++i) {
       const int m = SP ? kb + xr * X_PER + i : kb + xr + i * XROWS;
@@ -163,8 +170,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs pin) {
       }
     };
     for (int kb = kbeg; kb < kend; kb += 32) {
-      sp_store(Yp, TM * 32, yc, yr, ry);
-      sp_store(Xp, TN * 32, xc, xr, rx);
+      if (stage_y) sp_store(Yp, TM * 32, yc, yr, ry);
+      if (stage_x) sp_store(Xp, TN * 32, xc, xr, rx);
       __syncthreads();
 #pragma unroll
       for (int k16 = 0; k16 < 2; ++k16) {
@@ -693,6 +700,10 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   }
   const bool dma_ok = (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
   const bool sp = big && arith == SEMSEG_ARITH_BF16X3;   // 128 x 128 tiles with split-bf16 products
+  // 64 x 64 tiles under bf16x3: the SP instance of the register-staged kernel (SEMSEG_WGRAD_SP64=0: the exact-fp32 kernel,
+  // what rounds 3-4 ran these tiles on)
+  const char* sp64_s = getenv("SEMSEG_WGRAD_SP64");
+  const bool sp64 = !big && arith == SEMSEG_ARITH_BF16X3 && !(sp64_s && sp64_s[0] == '0');
   // bf16x3 variants: 8 / 9 = the direct-to-LDS ring with the split at fragment time (4 stages, 2 workgroups per CU / 3
   // stages, 3 per CU); 0 = the register-staged SP kernel of round 3.  SEMSEG_WGRAD_SP = 0 | 8 | 9 (A/B, tests).
   const char* sp_s = getenv("SEMSEG_WGRAD_SP");
@@ -757,7 +768,12 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   else if (big && dma == 5) LAUNCH_WGRAD_DMA(8, 4, 4, false);
   else if (big && dma == 6) LAUNCH_WGRAD_DMA(16, 4, 2, true);    // 3 + two-level accumulation
   else if (big && dma == 7) LAUNCH_WGRAD_DMA(32, 2, 2, true);    // 1 + two-level accumulation
-  else if (big) LAUNCH_WGRAD(128, 128); else LAUNCH_WGRAD(64, 64);
+  else if (big) LAUNCH_WGRAD(128, 128);
+  else if (sp64) {
+    if (mode == 1) conv_wgrad_kernel<64, 64, 1, 3><<<grid, 256, 0, stream>>>(a);
+    else if (mode == 2) conv_wgrad_kernel<64, 64, 2, 3><<<grid, 256, 0, stream>>>(a);
+    else conv_wgrad_kernel<64, 64, 0, 3><<<grid, 256, 0, stream>>>(a);
+  } else LAUNCH_WGRAD(64, 64);
 #undef LAUNCH_WGRAD_DMA_SP
 #undef LAUNCH_WGRAD_DMA
 #undef LAUNCH_WGRAD

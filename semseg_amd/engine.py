@@ -576,7 +576,7 @@ class Engine:
     @staticmethod
     def _wgrad_family(big, arith):
         if not big:
-            return "conv_wgrad_kernel<64,64>+reduce"
+            return "conv_wgrad_kernel<64,64%s>+reduce" % _fam(arith)
         return "conv_wgrad_dma_kernel<128x128%s>+reduce" % _fam(arith)
 
     def _conv_bwd(self, x, y, cl, m):

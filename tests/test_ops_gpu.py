@@ -1109,6 +1109,40 @@ def test_conv_wgrad_arith_bf16x3(case, sp_variant, report, monkeypatch):
     assert errs[1] <= 2 * errs[0] + 1e-7
 
 
+@pytest.mark.parametrize("case", [(2, 23, 21, 64, 64, 3, 1, 1, 1),       # "same" 3x3, 64 -> 64 (layer0 / layer1 conv2): linear gather
+                                  (2, 23, 21, 64, 256, 1, 1, 0, 1),      # 1x1, 64 input channels
+                                  (2, 21, 21, 256, 64, 1, 2, 0, 1),      # strided 1x1, 64 output channels: generic gather
+                                  (1, 33, 33, 64, 128, 3, 1, 1, 1),      # layer0.6: 64 -> 128, M = 1089 (K tail)
+                                  (2, 15, 15, 256, 256, 1, 1, 0, 1)])    # a 128-multiple layer on a grid small enough for the 64 x 64 rule
+def test_conv_wgrad_arith_bf16x3_64_tiles(case, report, monkeypatch):
+    """The SP instance of the 64 x 64 register-staged weight-gradient kernel (waves 0-1 stage dy, waves 2-3 stage x) under
+    SEMSEG_ARITH_BF16X3, next to the exact-fp32 64 x 64 kernel (SEMSEG_WGRAD_SP64=0) on the same operands, against fp64: rms
+    within 2x of the fp32 kernel's (+1e-7), the criterion of the 128 x 128 instances."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co, k, s_, p_, d = case
+    g = torch.Generator().manual_seed(37)
+    x = torch.relu(torch.randn(N, Ci, H, W, generator=g))
+    Ho, Wo = ops.conv_out(H, k, s_, p_, d), ops.conv_out(W, k, s_, p_, d)
+    dy = torch.randn(N, Co, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, k, k), dy.double(), stride=s_, padding=p_, dilation=d)
+    ldx, ldy = Ci + 32, ops.roundup(Co, 128)
+    xd = torch.randn(N, H, W, ldx, device=DEV)
+    xd[..., :Ci] = nhwc(x).to(DEV)
+    dyd = torch.zeros(N, Ho, Wo, ldy, device=DEV)
+    dyd[..., :Co] = nhwc(dy).to(DEV)
+    scratch = torch.empty(1 << 24, device=DEV)
+    rms = lambda a: float((a.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    errs = []
+    for sp64 in ("0", "1"):
+        monkeypatch.setenv("SEMSEG_WGRAD_SP64", sp64)
+        dw = torch.full((Co, Ci, k, k), float("nan"), device=DEV)
+        ops.conv_wgrad(xd, ldx, dyd, ldy, dw, scratch, N, H, W, Ci, Co, k, k, s_, p_, d, arith=ops.ARITH_BF16X3)
+        torch.cuda.synchronize()
+        errs.append(rms(dw))
+    report("conv_wgrad bf16x3 on 64x64 tiles %s: rms %.2e (exact-fp32 64x64 kernel %.2e)" % (case, errs[1], errs[0]))
+    assert errs[1] <= 2 * errs[0] + 1e-7 and errs[1] < 2e-5
+
+
 @pytest.mark.parametrize("case", [(3, 13, 11, 128, 128, 3, 1, 2, 2), (2, 21, 21, 128, 256, 3, 2, 1, 1)])
 def test_conv_arith_bf16x3_3x3(case, report):
     """SEMSEG_ARITH_BF16X3 per launch: the SP instances of the 3x3 (unrolled-tap) forward / data-gradient kernel, dilated
