@@ -1169,7 +1169,7 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
     // the 256 x 128 bf16x3 GEMM kernel (gemm_bf16split.hip) for what is a plain row GEMM with statistics: 1x1, stride 1, no
     // padding, nothing folded into the epilogue, whole 128-column panels; anything else runs the 128 x 128 implicit-GEMM tile
     const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W && !bias && !scale && !relu && !add;
-    if (arith == SEMSEG_ARITH_BF16X3 && plain && Co % 128 == 0 && (ldy & 3) == 0 && ldy >= Co && ((size_t)y & 15) == 0)
+    if (arith == SEMSEG_ARITH_BF16X3 && plain && Co % 128 == 0 && (ldy & 3) == 0 && ldy >= Co && (((size_t)y | (size_t)x) & 15) == 0)
       return semseg_split_gemm_conv1x1_fwd(x, ldx, w_fwd, y, ldy, a.M, Ci, Co, stats, a.stats_nslot, stream);
     tile_n = 128;
   }
@@ -1191,7 +1191,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx
     // maximum, against 1.2 x / 1.6 x with flushing — inside the 3 x / 5 x criterion, and K <= 1024 keeps it to the layers
     // where the kernel pays (layer3's conv3: 215 -> 178 us).  Anything else runs the 128 x 128 implicit-GEMM tile.
     const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W;
-    const bool al = (lddx & 3) == 0 && lddx >= Ci && ((size_t)dx & 15) == 0 && (!add || ((ldadd & 3) == 0 && ((size_t)add & 15) == 0));
+    const bool al = (lddx & 3) == 0 && lddx >= Ci && (((size_t)dx | (size_t)dy) & 15) == 0 && (!add || ((ldadd & 3) == 0 && ((size_t)add & 15) == 0));
     if (arith == SEMSEG_ARITH_BF16X3 && plain && al && Ci % 128 == 0 && Kc <= 1024 && (!bnr || bnr->bnr_n == 1)) {
       const bool on = bnr != nullptr;
       return semseg_split_gemm_conv1x1_dgrad(dy, lddy, w_dgrad, dx, lddx, N * H * W, Kc, Ci, add, ldadd,
