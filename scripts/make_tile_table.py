@@ -50,7 +50,7 @@ if __name__ == "__main__":
         del tr, m, x, y
         torch.cuda.empty_cache()
     tiles = dict(sorted((k, v) for k, v in ops.TILE_CHOICE.items() if k.endswith("|sp") == SPLIT))
-    doc = {"generated_by": "scripts/make_tile_table.py (3 x 3 launches per tile shape; 128 x 128 unless another wins by >= 3 %)",
+    doc = {"generated_by": "scripts/make_tile_table.py (3 x 3 launches per tile shape; 128 x 128 unless another wins by >= 3 %, code 2128 by >= 2 %)",
            "tile_codes": "128 = 128x128, 64 = 128x64, 1128 = 64x128, 1064 = 64x64 (rows x columns); 2128 = forward of a 1x1 "
                          "stride-1 conv on the 256x128 bf16x3 GEMM kernel (gemm_bf16split.hip)",
            "configs": ["%s%d_%d_c%d_bs%d" % c for c in CONFIGS],
