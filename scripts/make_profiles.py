@@ -10,6 +10,7 @@ def family(k):
     """Template instantiations that bench.py's KernelTimer reports as one family: the weight-gradient kernel's
     addressing MODE and the forward/data-gradient kernel's two-level-accumulation flag are dropped; the SP = 3
     (SEMSEG_ARITH_BF16X3) instances keep an SP3 tag, as in the KernelTimer labels."""
+    if k.startswith('conv_wgrad_dma_wide_kernel<'): return 'conv_wgrad_dma_wide_kernel<128x256,SP3>'
     m = re.match(r'conv_wgrad_dma_kernel<\d+, \d+, \d+, \d+, (?:true|false)(?:, (\d))?>', k)
     if m: return 'conv_wgrad_dma_kernel<128x128%s>' % (',SP3' if m.group(1) == '3' else '')
     m = re.match(r'conv_wgrad_kernel<(\d+), (\d+), \d+(?:, (\d))?>', k)
@@ -85,7 +86,7 @@ if os.path.exists(sp):
         fo.write("family,calls,total_ms,avg_us\n")
         for k, (c, t) in sorted(fs.items(), key=lambda kv: -kv[1][1]):
             fo.write('"%s",%d,%.3f,%.2f\n' % (k, c, t / 1e6, t / c / 1e3))
-    w2 = fs.get('conv_wgrad_dma_kernel<128x128,SP3>') or fs.get('conv_wgrad_dma_kernel<128x128>'); r2 = fs.get('wgrad_reduce_unpack_kernel')
+    w2 = fs.get('conv_wgrad_dma_wide_kernel<128x256,SP3>') or fs.get('conv_wgrad_dma_kernel<128x128,SP3>') or fs.get('conv_wgrad_dma_kernel<128x128>'); r2 = fs.get('wgrad_reduce_unpack_kernel')
     if w2: print("serialized rocprof: 128x128 weight-gradient kernel avg %.1f us over %d launches (+ reduce %.1f us)" % (w2[1] / w2[0] / 1e3, w2[0], r2[1] / r2[0] / 1e3 if r2 else 0))
-wg = fam.get('conv_wgrad_dma_kernel<128x128,SP3>') or fam.get('conv_wgrad_dma_kernel<128x128>'); ru = fam.get('wgrad_reduce_unpack_kernel')
+wg = fam.get('conv_wgrad_dma_wide_kernel<128x256,SP3>') or fam.get('conv_wgrad_dma_kernel<128x128,SP3>') or fam.get('conv_wgrad_dma_kernel<128x128>'); ru = fam.get('wgrad_reduce_unpack_kernel')
 if wg: print("rocprof family 128x128 weight-gradient kernel: avg %.1f us over %d launches (reduce kernel avg %.1f us)" % (wg[1] / wg[0] / 1e3, wg[0], ru[1] / ru[0] / 1e3 if ru else 0))

@@ -10,6 +10,13 @@ namespace {
 #ifndef SPLITK_BATCH
 #define SPLITK_BATCH 1   // split-K reductions: several slabs' loads in flight per trip (0 = one slab per trip; A/B builds)
 #endif
+#ifndef WGRAD_SP_POLICY
+#define WGRAD_SP_POLICY 10
+#endif
+#ifndef WIDE_NSTAGE
+#define WIDE_NSTAGE 4     // ring depth of the 128 x 256 kernel (24 KB per stage): 4 and 5 run the step equally fast, 6 (144 KB) loses the
+                          // whole gain — the LDS it leaves is what lets the main stream's kernels share the CU
+#endif
 #ifndef SP_PIPE
 #define SP_PIPE 1      // bf16x3 direct-to-LDS weight gradient: 0 = read -> split -> MFMA in sequence inside a stage (A/B builds)
 #endif
@@ -586,6 +593,219 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16x3 weight gradient with a 64 x 128 wave tile (128 x 256 workgroup tile, 4 waves, ONE workgroup per CU).
+// The 128 x 128 kernel above splits 32 floats per lane for 24 matrix-core instructions per stage (2 + 2 fragments); its
+// matrix pipe is busy 0.51 by PMC and it waits on VALU issue.  With a 64 x 128 wave tile a lane splits 48 floats for 48
+// instructions (2 + 4 fragments): two thirds of the conversion work per product.  Price: 128 accumulator registers and a
+// 24 KB stage, i.e. one wave per SIMD — every VALU instruction of the split has to hide behind the matrix-core instructions of
+// the SAME wave (the software-pipelined loop of the kernel above: fragments of stage t + 1 are read and split while the 48
+// instructions of stage t issue), nothing else of THIS kernel is resident to cover a stall.  Same ring, same DMA stream, same
+// slab layout.  Measured: alone it runs at the rate of the 128 x 128 kernel (172 vs 169 TFLOP/s fp32-equivalent on layer3's
+// shapes, 180 vs 181 on cls.0 — both at what the chip sustains for six-product work), but the STEP is 3.8 % faster with it
+// (118.8-119.0 -> 114.4-114.5 ms): weight gradients run on the side stream next to the data-gradient / BatchNorm chain, and
+// four waves and 96 KB per CU leave that chain the issue slots and the LDS that eight waves and 128 KB did not.
+// x rows are 256 floats = 1 KiB = one wave-instruction per pixel, so the gather decode of a DMA instruction is wave-uniform.
+// ------------------------------------------------------------------------------------------
+template <int MODE, int NSTAGE>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const WgradArgs pin) {
+  WgradArgs p = pin;
+  if (p.batch > 1) {
+    const long long bz = blockIdx.y;
+    p.x += bz * p.x_bs;
+    p.dy += bz * p.dy_bs;
+    p.dw += bz * p.dw_bs;
+  }
+  constexpr int KS = 16, TM = 128, TN = 256;
+  constexpr int STAGE_F = KS * (TM + TN);
+  constexpr int NIY = 2, NIX = 4;          // DMA instructions per wave and stage: dy (2 k-rows each), x (1 k-row each)
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_F];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int RS = p.R * p.S;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_ks = p.tiles_ci * p.tiles_co * RS;
+  const int ks = b / per_ks;
+  b -= ks * per_ks;
+  int tci, tco, tap;
+  if (p.order == 1) {
+    tap = b % RS; b /= RS;
+    tco = b % p.tiles_co;
+    tci = b / p.tiles_co;
+  } else if (p.order == 2) {
+    tap = b % RS; b /= RS;
+    tci = b % p.tiles_ci;
+    tco = b / p.tiles_ci;
+  } else {
+    tci = b % p.tiles_ci; b /= p.tiles_ci;
+    tco = b % p.tiles_co;
+    tap = b / p.tiles_co;
+  }
+  const int r = tap / p.S, s = tap - r * p.S;
+  const int co0 = tco * TM, ci0 = tci * TN;
+  const int kbeg = ks * p.kper;
+  const int kend = min(p.M, kbeg + p.kper);
+  const int hw = p.Ho * p.Wo;
+
+  const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.dy, 0, (int)min((size_t)0x7FFFFFFFu, (size_t)p.M * p.lddy * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.x, 0, (int)min((size_t)0x7FFFFFFFu, (size_t)p.N * p.Hin * p.Win * p.ldx * 4), 0x00020000);
+
+  // dy: this lane's k-row inside a stage is wave * 4 + lhi (+ 2 i), 16-byte column l31 * 4
+  unsigned yoff[NIY];
+#pragma unroll
+  for (int i = 0; i < NIY; ++i) yoff[i] = (unsigned)(((kbeg + wave * 4 + lhi + 2 * i) * p.lddy + co0 + l31 * 4) * 4);
+  const unsigned ystep = (unsigned)(KS * p.lddy * 4);
+  // x: k-row wave * 4 + i, 16-byte column lane * 4
+  const int tapoff = ((r * p.dil - p.pad) * p.Win + (s * p.dil - p.pad)) * p.ldx + ci0 + lane * 4;
+  unsigned xoff[NIX];
+#pragma unroll
+  for (int i = 0; i < NIX; ++i) xoff[i] = (unsigned)(((kbeg + wave * 4 + i) * p.ldx + tapoff) * 4);
+  const unsigned xstep = (unsigned)(KS * p.ldx * 4);
+
+  auto issue = [&](int kb, int slot) {
+    float* Ysl = smem + slot * STAGE_F;
+    float* Xsl = Ysl + KS * TM;
+#pragma unroll
+    for (int i = 0; i < NIY; ++i) {
+      dma16_to_lds(ry_, Ysl + (wave * 4 + 2 * i) * TM, yoff[i]);
+      yoff[i] += ystep;
+    }
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+      unsigned vo;
+      if constexpr (MODE == 1) {
+        vo = xoff[i];
+      } else {
+        const int m = kb + wave * 4 + i;          // one pixel per instruction: wave-uniform
+        const int mm = m < kend ? m : kbeg;
+        const int n = fdiv(mm, p.div_hw);
+        const int rem = mm - n * hw;
+        const int oh = fdiv(rem, p.div_wo);
+        const int ow = rem - oh * p.Wo;
+        const int ih = oh * p.stride + r * p.dil - p.pad;
+        const int iw = ow * p.stride + s * p.dil - p.pad;
+        const bool ok = m < kend && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        if constexpr (MODE == 2)
+          vo = ok ? xoff[i] : OOB;
+        else
+          vo = ok ? (unsigned)((((n * p.Hin + ih) * p.Win + iw) * p.ldx + ci0 + lane * 4) * 4) : OOB;
+      }
+      dma16_to_lds(rx_, Xsl + (wave * 4 + i) * TN, vo);
+      xoff[i] += xstep;
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  // raw fp32 fragments of a stage: the 8 pixels of this lane's k-group for its 2 dy rows (2 l31 + i) and 4 x columns (4 l31 + j)
+  auto sp_read = [&](int slot, f32x2 (&ya)[8], f32x4 (&xa)[8]) {
+    const float* Ya = smem + slot * STAGE_F + (lhi * 8) * TM + wm * 64 + 2 * l31;
+    const float* Xa = smem + slot * STAGE_F + KS * TM + (lhi * 8) * TN + wn * 128 + 4 * l31;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      ya[kk] = *reinterpret_cast<const f32x2*>(Ya + kk * TM);
+      xa[kk] = *reinterpret_cast<const f32x4*>(Xa + kk * TN);
+    }
+  };
+  auto split8 = [&](f32x8 v, bf16x8 (&out)[3]) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      out[pc] = __builtin_convertvector(v, bf16x8);
+      if (pc < 2) v -= bf16x8_to_f32(out[pc]);
+    }
+  };
+  auto sp_split = [&](const f32x2 (&ya)[8], const f32x4 (&xa)[8], bf16x8 (&fa2)[2][3], bf16x8 (&fb2)[4][3]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x8 va;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) va[kk] = ya[kk][i];
+      split8(va, fa2[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x8 vb;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) vb[kk] = xa[kk][j];
+      split8(vb, fb2[j]);
+    }
+  };
+  auto sp_mfma = [&](const bf16x8 (&fa2)[2][3], const bf16x8 (&fb2)[4][3]) {
+    // small terms first, the leading product last; consecutive instructions go to different accumulators
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i][PA[q]], fb2[j][PB[q]], acc[i][j], 0, 0, 0);
+  };
+
+  const int nsteps = (kend - kbeg + KS - 1) / KS;
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) issue(kbeg + st * KS, st);
+  bf16x8 fca[2][3], fcb[4][3];
+  {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NIY + NIX) * (NSTAGE - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x2 ya[8];
+    f32x4 xa[8];
+    sp_read(0, ya, xa);
+    sp_split(ya, xa, fca, fcb);
+  }
+  int nslot_ = 1, pslot_ = NSTAGE - 1;
+  for (int t = 0; t < nsteps; ++t) {
+    // stage t + 1 has landed for this wave once at most NSTAGE - 3 younger stages are outstanding, for every wave after the
+    // barrier — which also says that everybody finished reading stage t (in iteration t - 1): its slot may be overwritten
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NIY + NIX) * (NSTAGE - 3)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(kbeg + (t + NSTAGE - 1) * KS, pslot_);
+    f32x2 ya[8];
+    f32x4 xa[8];
+    bf16x8 fna[2][3], fnb[4][3];
+    sp_read(nslot_, ya, xa);        // stage t + 1 (past the end of the split: another split's rows or zeros, never used)
+    sp_mfma(fca, fcb);
+    sp_split(ya, xa, fna, fnb);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fca[i][pc] = fna[i][pc];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fcb[j][pc] = fnb[j][pc];
+    }
+    pslot_ = pslot_ + 1 == NSTAGE ? 0 : pslot_ + 1;
+    nslot_ = nslot_ + 1 == NSTAGE ? 0 : nslot_ + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the workgroup has retired
+
+  float* out = p.dw + (size_t)ks * p.Co_pad * RS * p.Ci;
+  const int ci = ci0 + wn * 128 + 4 * l31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rr = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      const int co = co0 + wm * 64 + 2 * rr + i;
+      const f32x4 v = {acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]};
+      *reinterpret_cast<f32x4*>(out + ((size_t)co * RS + tap) * p.Ci + ci) = v;
+    }
+}
+
 // dW partial slabs [ksplit][Co_pad][RS][Ci] -> OIHW gradient [Co][Ci][R][S] (sum over ksplit, in slab order:
 // deterministic).  Threads walk the SLAB layout, four input channels per thread: the ksplit reads (the bulk of the
 // traffic) are 16-byte coalesced, the four OIHW stores are RS floats apart (round 1 walked the OIHW order: for 3x3
@@ -653,7 +873,12 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   const char* small_s = getenv("SEMSEG_WGRAD_SMALL");   // "0": never fall back to 64 x 64 tiles (tests / tuning)
   const bool allow_small = !(small_s && small_s[0] == '0');
   const bool big = (Ci % 128 == 0) && (Co >= 128) && !(allow_small && small_tiles);
-  const int TM = big ? 128 : 64, TN = big ? 128 : 64;
+  // bf16x3 variant 10: the 128 x 256 kernel (64 x 128 wave tiles, one workgroup per CU); needs 256-channel column tiles
+  const char* sp_s0 = getenv("SEMSEG_WGRAD_SP");
+  const int sp_env0 = sp_s0 ? atoi(sp_s0) : WGRAD_SP_POLICY;
+  const bool wide = big && arith == SEMSEG_ARITH_BF16X3 && sp_env0 == 10 && Ci % 256 == 0 &&
+                    (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
+  const int TM = big ? 128 : 64, TN = wide ? 256 : (big ? 128 : 64);
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = scratch; a.ldx = ldx; a.lddy = lddy;
   a.N = N; a.Hin = H; a.Win = W; a.Ho = Ho; a.Wo = Wo; a.Ci = Ci;
@@ -685,9 +910,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
 #ifndef WGRAD_DMA_POLICY
 #define WGRAD_DMA_POLICY "6"
 #endif
-#ifndef WGRAD_SP_POLICY
-#define WGRAD_SP_POLICY 8
-#endif
+
 
   const char* dma_s = getenv("SEMSEG_WGRAD_DMA");
   if (!dma_s) dma_s = WGRAD_DMA_POLICY;
@@ -705,12 +928,13 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   const char* sp64_s = getenv("SEMSEG_WGRAD_SP64");
   const bool sp64 = !big && arith == SEMSEG_ARITH_BF16X3 && !(sp64_s && sp64_s[0] == '0');
   // bf16x3 variants: 8 / 9 = the direct-to-LDS ring with the split at fragment time (4 stages, 2 workgroups per CU / 3
-  // stages, 3 per CU); 0 = the register-staged SP kernel of round 3.  SEMSEG_WGRAD_SP = 0 | 8 | 9 (A/B, tests).
+  // stages, 3 per CU); 10 (the policy) = the 128 x 256 kernel with 64 x 128 wave tiles for layers with Ci % 256 == 0 and
+  // variant 8 for the rest; 0 = the register-staged SP kernel of round 3.  SEMSEG_WGRAD_SP = 0 | 8 | 9 | 10 (A/B, tests).
   const char* sp_s = getenv("SEMSEG_WGRAD_SP");
   const int sp_env = sp_s ? atoi(sp_s) : WGRAD_SP_POLICY;
-  const int sp_dma = (sp && dma_ok && (sp_env == 8 || sp_env == 9)) ? sp_env : 0;
+  const int sp_dma = wide ? 10 : (sp && dma_ok && (sp_env == 8 || sp_env == 9 || sp_env == 10)) ? (sp_env == 10 ? 8 : sp_env) : 0;
   const int dma = sp ? sp_dma : ((big && dma_ok && dma_env >= 0 && dma_env <= 7) ? dma_env : 0);
-  static const int occ_of[10] = {3, 2, 3, 2, 5, 5, 2, 2, 2, 3};
+  static const int occ_of[11] = {3, 2, 3, 2, 5, 5, 2, 2, 2, 3, 1};
   // Fill whole residency rounds (256 CUs x resident workgroups per CU): among the K splits that give at most two
   // rounds, take the one with the best fill (ties: fewer splits = fewer slabs to write and reduce).
   const int ROUND = 256 * occ_of[dma];
@@ -755,7 +979,11 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
     else if (mode == 2) conv_wgrad_dma_kernel<2, 16, NST_, OCC_, false, 3><<<grid, 256, 0, stream>>>(a);  \
     else conv_wgrad_dma_kernel<0, 16, NST_, OCC_, false, 3><<<grid, 256, 0, stream>>>(a);                 \
   } while (0)
-  if (sp && sp_dma == 8) LAUNCH_WGRAD_DMA_SP(4, 2);
+  if (sp && sp_dma == 10) {
+    if (mode == 1) conv_wgrad_dma_wide_kernel<1, WIDE_NSTAGE><<<grid, 256, 0, stream>>>(a);
+    else if (mode == 2) conv_wgrad_dma_wide_kernel<2, WIDE_NSTAGE><<<grid, 256, 0, stream>>>(a);
+    else conv_wgrad_dma_wide_kernel<0, WIDE_NSTAGE><<<grid, 256, 0, stream>>>(a);
+  } else if (sp && sp_dma == 8) LAUNCH_WGRAD_DMA_SP(4, 2);
   else if (sp && sp_dma == 9) LAUNCH_WGRAD_DMA_SP(3, 3);
   else if (sp) {
     if (mode == 1) conv_wgrad_kernel<128, 128, 1, 3><<<grid, 256, 0, stream>>>(a);

@@ -558,7 +558,7 @@ class Engine:
         big = cl.Ci % 128 == 0 and cl.Co >= 128
         # 128 x 128 tiles run the direct-to-LDS kernel (conv_wgrad.hip: WGRAD_DMA_POLICY; under bf16x3 its SP = 3 form,
         # WGRAD_SP_POLICY) and 64 x 64 tiles the register-staged fp32 kernel
-        ev = self._t0(self._wgrad_family(big, cl.arith), flops)
+        ev = self._t0(self._wgrad_family(big, cl.arith, cl.Ci), flops)
         ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
                        cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil, arith=cl.arith)
         self._t1(ev)
@@ -574,9 +574,12 @@ class Engine:
         self._ready(ready)
 
     @staticmethod
-    def _wgrad_family(big, arith):
+    def _wgrad_family(big, arith, Ci=0):
         if not big:
             return "conv_wgrad_kernel<64,64%s>+reduce" % _fam(arith)
+        # conv_wgrad.hip: WGRAD_SP_POLICY 10 = the 128 x 256 kernel for layers with Ci % 256 == 0 (SEMSEG_WGRAD_SP overrides)
+        if arith == ops.ARITH_BF16X3 and Ci % 256 == 0 and Ci > 0 and os.environ.get("SEMSEG_WGRAD_SP", "10") == "10":
+            return "conv_wgrad_dma_wide_kernel<128x256,SP3>+reduce"
         return "conv_wgrad_dma_kernel<128x128%s>+reduce" % _fam(arith)
 
     def _conv_bwd(self, x, y, cl, m):
@@ -682,7 +685,7 @@ class Engine:
             ev = self._t0(WINO_HBM, -4.0 * (px * cl.Co + 16 * T * cl.Co))
             ops.wino_dy_transform_wgrad(dy, y.ld, Yh, cl.Co, N, H, W, cl.Co, d)
             self._t1(ev)
-            ev = self._t0(self._wgrad_family(True, cl.arith), gflops)
+            ev = self._t0(self._wgrad_family(True, cl.arith, cl.Ci), gflops)
             ops.gemm_kmajor_batched(V, cl.Ci, T * cl.Ci, Yh, cl.Co, T * cl.Co, dU, cl.Co * cl.Ci, scr, T, cl.Ci, cl.Co, 16,
                                     arith=cl.arith)
             self._t1(ev)

@@ -1080,14 +1080,15 @@ def test_conv_arith_bf16x3_1x1(code, report, monkeypatch):
 
 @pytest.mark.parametrize("case", [(2, 23, 21, 256, 128, 1, 1, 0, 1), (2, 19, 17, 128, 256, 3, 1, 2, 2), (2, 21, 21, 256, 256, 1, 2, 0, 1),
                                   (1, 33, 33, 128, 128, 3, 1, 1, 1)])
-@pytest.mark.parametrize("sp_variant", [8, 9, 0])
+@pytest.mark.parametrize("sp_variant", [8, 9, 0, 10])
 def test_conv_wgrad_arith_bf16x3(case, sp_variant, report, monkeypatch):
     """SEMSEG_ARITH_BF16X3 per launch: the SP instance of the 128 x 128 weight-gradient kernel (pixel-contiguous bf16
     piece planes, six bf16 matrix-core products) in its three gather modes (1x1, "same" 3x3 with dilation, strided)
     next to the fp32 kernels on the same operands, against fp64: rms within 2x of the fp32 path's (+1e-7)."""
     from semseg_amd import ops
     monkeypatch.setenv("SEMSEG_WGRAD_SMALL", "0")          # keep the 128 x 128 path on these small grids
-    # 8 / 9: the direct-to-LDS ring with the split at fragment time (4 stages / 3 stages); 0: the register-staged SP kernel
+    # 8 / 9: the direct-to-LDS ring with the split at fragment time (4 stages / 3 stages); 0: the register-staged SP kernel;
+    # 10: the 128 x 256 kernel with 64 x 128 wave tiles (layers with Ci % 256 == 0, else variant 8)
     monkeypatch.setenv("SEMSEG_WGRAD_SP", str(sp_variant))
     N, H, W, Ci, Co, k, s_, p_, d = case
     g = torch.Generator().manual_seed(31)
