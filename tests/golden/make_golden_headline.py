@@ -11,7 +11,11 @@ reference (/root/reference, imported here on CPU):
                                 restated from their formula there, that part stays "parity unpinned")
 
 Run in the build container only (needs ~50 GB of RAM for the batch-16 step):
-    python tests/golden/make_golden_headline.py [train] [ms]
+    python tests/golden/make_golden_headline.py [train] [ms] [psa]
+
+  psanet101_c150_s465_b16.npz   BASELINE configs[3] at its stated size: PSANet-101, 465x465, 150 classes, psa_type 2,
+                                shrink 2, full 59x59 mask, BATCH 16 train step (model/psanet.py:154-179): same contents
+                                plus the gradients of the PSA module's last layers
 The fixtures travel to the GPU box; /root/reference does not.
 """
 import os
@@ -38,9 +42,19 @@ def headline_inputs(batch, size, classes, zoom=8):
     return x, y
 
 
-def train_fixture(rp, segnet):
-    layers, classes, size, batch = 101, 150, 473, 16
-    m = rp.PSPNet(layers=layers, classes=classes, zoom_factor=8, dropout=0.0, pretrained=False)
+PSA_CFG = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=59, mask_w=59, normalization_factor=1.0,
+               psa_softmax=True)
+
+
+def train_fixture(rp, segnet, arch="psp"):
+    layers, classes, batch = 101, 150, 16
+    size = 473 if arch == "psp" else 465
+    psa_cfg = None if arch == "psp" else PSA_CFG
+    out_name = "pspnet101_c150_s473_b16.npz" if arch == "psp" else "psanet101_c150_s465_b16.npz"
+    if arch == "psp":
+        m = rp.PSPNet(layers=layers, classes=classes, zoom_factor=8, dropout=0.0, pretrained=False)
+    else:
+        m = rp.PSANet(layers=layers, classes=classes, zoom_factor=8, dropout=0.0, pretrained=False, **PSA_CFG)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = segnet.recipe_state_dict(shapes, seed=1234)
     m.load_state_dict(sd)
@@ -52,8 +66,8 @@ def train_fixture(rp, segnet):
     pred, ml, al = m(x, y)
     hook.remove()
     (ml + 0.4 * al).backward()
-    print("reference PSPNet-101 473^2 batch 16 train step on the CPU: %.1f s, main %.6f aux %.6f"
-          % (time.time() - t0, ml.item(), al.item()), flush=True)
+    print("reference %s-101 %d^2 batch 16 train step on the CPU: %.1f s, main %.6f aux %.6f"
+          % ("PSPNet" if arch == "psp" else "PSANet", size, time.time() - t0, ml.item(), al.item()), flush=True)
     grads = {k: p.grad.clone() for k, p in m.named_parameters()}
     new_sd = {k: v.clone() for k, v in m.state_dict().items()}
     # top-2 margin of the reference's own upsampled train-mode scores at the sampled pixels, relative to max |score|: an
@@ -73,21 +87,30 @@ def train_fixture(rp, segnet):
     names = list(grads)
     fx["gnorm_names"] = np.array(names)
     fx["gnorm"] = np.array([grads[k].double().norm().item() for k in names])
-    for k in ["cls.4.weight", "cls.4.bias", "aux.4.weight", "aux.4.bias", "layer0.1.weight", "layer0.1.bias"]:
-        fx["grad/" + k] = grads[k].numpy()
-    for k in ["layer0.1.running_mean", "layer0.1.running_var", "layer4.2.bn3.running_var", "cls.1.running_mean"]:
+    head = ["cls.4.weight", "cls.4.bias", "aux.4.weight", "aux.4.bias", "layer0.1.weight", "layer0.1.bias"]
+    bufs = ["layer0.1.running_mean", "layer0.1.running_var", "layer4.2.bn3.running_var", "cls.1.running_mean"]
+    if arch == "psa":   # the PSA module's own last layers (model/psanet.py:29-51) and one of its BatchNorms
+        head += ["psa.proj.0.weight", "psa.attention.3.weight", "psa.attention_p.3.weight"]
+        bufs += ["psa.proj.1.running_var"]
+    for k in head:
+        if grads[k].numel() > (1 << 20):   # the PSA module's big 1x1 weights: a [::8, ::8] sample and the full maximum
+            fx["gradsub/" + k] = grads[k].numpy()[::8, ::8].copy()
+            fx["gradmax/" + k] = np.float64(grads[k].abs().max().item())
+        else:
+            fx["grad/" + k] = grads[k].numpy()
+    for k in bufs:
         fx["buf/" + k] = new_sd[k].numpy()
     del m, pred, grads
     # the oracle on the same step: pins oracle/segnet.py to the reference at the headline configuration too
     sd_t = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
             for k, v in sd.items()}
-    p2, ml2, al2 = segnet.forward(sd_t, x, layers, "psp", zoom_factor=8, training=True, y=y)
+    p2, ml2, al2 = segnet.forward(sd_t, x, layers, arch, zoom_factor=8, training=True, y=y, psa_cfg=psa_cfg)
     assert ml2.item() == fx["main_loss"] and al2.item() == fx["aux_loss"], "oracle != reference at batch 16"
     assert np.array_equal(p2[:, ::5, ::5].numpy().astype(np.uint8), fx["pred_sample"])
     for k in ["layer0.1.running_mean", "layer4.2.bn3.running_var", "cls.1.running_mean"]:
         assert torch.equal(sd_t[k], new_sd[k]), k
-    np.savez_compressed(os.path.join(HERE, "pspnet101_c150_s473_b16.npz"), **fx)
-    print("pspnet101_c150_s473_b16.npz written; oracle == reference (losses, argmax sample, running statistics)", flush=True)
+    np.savez_compressed(os.path.join(HERE, out_name), **fx)
+    print(out_name + " written; oracle == reference (losses, argmax sample, running statistics)", flush=True)
 
 
 def ms_fixture(rp, segnet):
@@ -138,7 +161,7 @@ def ms_fixture(rp, segnet):
 def main():
     what = sys.argv[1:] or ["train", "ms"]
     resource.setrlimit(resource.RLIMIT_AS, (58 << 30, 58 << 30))   # fail with MemoryError instead of waking the OOM killer
-    rp, _, _ = import_reference()
+    rp, rpa, _ = import_reference()
     sys.path.insert(0, ROOT)
     from oracle import segnet
     torch.manual_seed(0)
@@ -147,6 +170,8 @@ def main():
         ms_fixture(rp, segnet)
     if "train" in what:
         train_fixture(rp, segnet)
+    if "psa" in what:
+        train_fixture(rpa, segnet, arch="psa")
 
 
 if __name__ == "__main__":

@@ -93,9 +93,10 @@ def _err(a, ref):
 
 
 class InsituChecker:
-    def __init__(self, eng, log=print):
+    def __init__(self, eng, log=print, only=None):
         self.eng = eng
         self.log = log
+        self.only = only     # callable(kind, module name or None) -> bool: ops it rejects run unchecked (batch-16 sampling)
         self.rows = []       # (kind, name, quantity, max_hip, max_cpu32, rms_hip, rms_cpu32)
         self.names = {m: n for n, m in eng.model.named_modules()}
         torch.set_num_threads(usable_cores())
@@ -103,6 +104,10 @@ class InsituChecker:
     # ------------------------------------------------------------------ hook
     def __call__(self, op):
         h = getattr(self, "_chk_" + op.kind, None)
+        if h is not None and self.only is not None:
+            mod = op.ctx.get("m") or op.ctx.get("bm")
+            if not self.only(op.kind, self.names.get(mod) if mod is not None else None):
+                h = None
         if h is None:
             op.fn()
             return
@@ -353,11 +358,11 @@ class InsituChecker:
         self._rec("psa", nm, "dmask", ym.grad[..., :ym.C].detach().cpu(), r64[1], r32[1])
 
 
-def run_insitu(model, x, y, log=print):
+def run_insitu(model, x, y, log=print, only=None):
     """One train step of `model` (cuda, train mode) with the checker installed; returns the checker."""
     from semseg_amd.engine import Engine
     eng = Engine(model, x.shape[0], x.shape[2], x.shape[3], True, model.kind)
-    chk = InsituChecker(eng, log)
+    chk = InsituChecker(eng, log, only)
     pred, ml, al = eng.forward_train(x, y, 255)
     eng.tape_hook = chk
     g_main = torch.ones(1, device=x.device)

@@ -4,6 +4,8 @@ imported reference itself (tests/golden/make_golden_headline.py, run in the buil
   * metric configuration: PSPNet-101, 473x473, 150 classes, BATCH 16 train step (model/pspnet.py:80-105) — through
     `Trainer.step` (what bench.py times) and through the drop-in nn.Module path (`loss.backward()`), in the default
     arithmetic (bf16x3) and with exact fp32 forced;
+  * configs[3] at its stated size (round 5): PSANet-101, 465x465, 150 classes, psa_type 2, shrink 2, full 59x59 mask, BATCH 16
+    (model/psanet.py:154-179), same four path x arithmetic combinations, same bounds;
   * configs[4]: the multi-scale test path (tool/test.py:149-204) on a 512x512 image, base_size 512, crop 473, the six ADE
     scales = 23 crops = 46 forwards through `MultiScaleTester`.
 
@@ -54,35 +56,51 @@ def _check_train(report, name, gold, pred, ml, al, grads, bufs):
     near_ties = float((gold["margin_sample"] < TIE).mean())
     e_buf = {k[4:]: _rel(bufs[k[4:]].cpu().numpy(), gold[k]) for k in gold.files if k.startswith("buf/")}
     e_grad = {k[5:]: _rel(grads[k[5:]].cpu().numpy(), gold[k]) for k in gold.files if k.startswith("grad/")}
+    for k in gold.files:       # big tensors are stored as a [::8, ::8] sample + the maximum of the whole tensor
+        if k.startswith("gradsub/"):
+            a = grads[k[8:]].cpu().numpy()[::8, ::8].astype(np.float64)
+            e_grad[k[8:]] = float(np.abs(a - gold[k]).max() / float(gold["gradmax/" + k[8:]]))
     names = [str(n) for n in gold["gnorm_names"]]
     gn = np.array([float(grads[n].double().norm().item()) for n in names])
     dev = np.abs(gn - gold["gnorm"]) / np.maximum(gold["gnorm"], 1e-30)
     q = lambda f: float(np.sort(dev)[min(len(dev) - 1, int(f * len(dev)))])
     report("%s vs the reference's batch-16 fixture: losses %.2e / %.2e, argmax sample agreement %.5f (%d of %d samples differ, "
            "largest reference margin among them %.1e of max |score|; %.2f %% of all samples are near-ties < %.0e), running "
-           "statistics %s, head gradients %s, gradient norms (340 tensors) median %.1e q90 %.1e max %.1e (%s)"
+           "statistics %s, head gradients %s, gradient norms (%d tensors) median %.1e q90 %.1e max %.1e (%s)"
            % (name, e_ml, e_al, agree, int((~same).sum()), same.size, worst_margin, 100 * near_ties, TIE,
               {k: "%.1e" % v for k, v in e_buf.items()}, {k: "%.1e" % v for k, v in e_grad.items()},
-              q(.5), q(.9), dev.max(), names[int(dev.argmax())]))
+              len(names), q(.5), q(.9), dev.max(), names[int(dev.argmax())]))
     assert e_ml < 1e-5 and e_al < 1e-5
     assert worst_margin < TIE and agree >= 0.99
     assert all(v < 1e-4 for v in e_buf.values()), e_buf
-    for k in ("cls.4.weight", "cls.4.bias", "aux.4.weight", "aux.4.bias"):
-        assert e_grad[k] < 5e-4, (k, e_grad[k])
+    for k, v in e_grad.items():
+        # last layers of the heads (and of the PSA module): 5e-4 of their maximum.  layer0.1 (the FIRST BatchNorm, 100 layers of
+        # ReLU-mask flips below the loss): two fp32 implementations differ element-wise by 8e-2 of the maximum there — the
+        # exact-fp32 path measured 7.9e-2 / 8.1e-2 against this fixture in round 4 (profiles/r04_parity_report.txt), bf16x3
+        # 8.3e-2 / 9.4e-2 — so the bound is twice the exact path's figure; the sharp per-op criterion at this batch is
+        # test_insitu_pspnet101_473_batch16_sampled (profiles/r05_insitu_b16.txt)
+        assert v < (1.6e-1 if k.startswith("layer0.") else 5e-4), (k, v)
     assert q(.5) <= 2e-3 and q(.9) <= 1e-2 and dev.max() <= 1e-1
+
+
+PSA_CFG = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=59, mask_w=59, normalization_factor=1.0, psa_softmax=True)
 
 
 @pytest.mark.skipif(os.environ.get("SEMSEG_SKIP_BIG_INSITU") == "1", reason="big cases disabled")
 @pytest.mark.parametrize("arith", ["bf16x3", "f32"])
 @pytest.mark.parametrize("path", ["trainer", "module"])
-def test_headline_batch16_train_step(path, arith, report):
+@pytest.mark.parametrize("config", ["pspnet101_473", "psanet101_465"])
+def test_headline_batch16_train_step(config, path, arith, report):
+    """BASELINE metric configuration (PSPNet-101 473^2) and configs[3] (PSANet-101 465^2, psa_type 2, shrink 2, 59x59 mask:
+    model/psanet.py:154-179) at their stated batch 16, against fixtures of the imported reference."""
     from semseg_amd import engine as E
     from semseg_amd.trainer import Trainer
-    gold = np.load(os.path.join(GOLD, "pspnet101_c150_s473_b16.npz"))
+    psa = config.startswith("psanet")
+    gold = np.load(os.path.join(GOLD, "psanet101_c150_s465_b16.npz" if psa else "pspnet101_c150_s473_b16.npz"))
     old = E.set_arith(arith)
     try:
-        m, _ = build("psp", 101, 150)
-        x, y = inputs(16, 473, 150)
+        m, _ = build("psa", 101, 150, **PSA_CFG) if psa else build("psp", 101, 150)
+        x, y = inputs(16, 465 if psa else 473, 150)
         m = m.cuda().train()
         xd, yd = x.cuda(), y.cuda()
         if path == "trainer":
@@ -98,7 +116,7 @@ def test_headline_batch16_train_step(path, arith, report):
             grads = {k: p.grad for k, p in m.named_parameters()}
         torch.cuda.synchronize()
         bufs = {k: v for k, v in m.state_dict().items() if "running" in k}
-        _check_train(report, "PSPNet-101 473^2 batch 16 [%s, %s]" % (path, arith), gold, pred, float(ml.item()),
+        _check_train(report, "%s batch 16 [%s, %s]" % ("PSANet-101 465^2" if psa else "PSPNet-101 473^2", path, arith), gold, pred, float(ml.item()),
                      float(al.item()), grads, bufs)
     finally:
         E.set_arith(old)

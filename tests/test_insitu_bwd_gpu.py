@@ -20,14 +20,14 @@ from test_model_gpu import build, inputs
 pytestmark = pytest.mark.gpu
 
 
-def _case(report, name, arch, layers, classes, size, batch, psa_cfg=None, oracle_loss=True):
+def _case(report, name, arch, layers, classes, size, batch, psa_cfg=None, oracle_loss=True, only=None):
     from oracle import segnet
     from insitu import run_insitu
     kw = dict(psa_cfg) if psa_cfg else {}
     m, sd = build(arch, layers, classes, **kw)
     x, y = inputs(batch, size, classes)
     m = m.cuda().train()
-    chk, ml, al = run_insitu(m, x.cuda(), y.cuda(), report)
+    chk, ml, al = run_insitu(m, x.cuda(), y.cuda(), report, only=only)
     report("in-situ backward parity, %s: %d quantities over %d ops\n%s"
            % (name, len(chk.rows), len({(r[0], r[1]) for r in chk.rows}), chk.summary()))
     if oracle_loss:
@@ -78,6 +78,27 @@ def test_insitu_pspnet101_473(arith, report):
     assert sum(1 for r in chk.rows if r[2].startswith("dgrad+bnr")) >= 90
     # ... including the 29 bn1 layers whose consumer conv2 runs the Winograd path (reduction in its output transform)
     assert sum(1 for r in chk.rows if r[2] == "dgrad+bnr-wino") == 29
+
+
+B16_SAMPLE = ("layer0.", "layer1.0.", "layer2.0.", "layer3.0.", "layer3.5.", "layer3.11.", "layer3.17.", "layer3.22.",
+              "layer4.0.", "layer4.1.", "layer4.2.", "ppm.", "cls.", "aux.")
+
+
+@pytest.mark.skipif(os.environ.get("SEMSEG_INSITU_B16") != "1",
+                    reason="opt-in (SEMSEG_INSITU_B16=1): ~10 min of CPU fp64 recomputation at the headline batch")
+def test_insitu_pspnet101_473_batch16_sampled(arith, report):
+    """the per-op criterion at the HEADLINE batch (16), once per arithmetic, same bounds as at batch 2.
+    The CPU recomputation of all 340 ops at batch 16 does not fit a GPU-box call, so the ops are sampled by module: the stem,
+    the first block of layer1 / layer2, five of layer3's 23 blocks (first, last, three between), all of layer4 (dilation 4,
+    Winograd), the pyramid, both heads (K = 36 864 / 9 216 Winograd convs) and every non-module op (max pool, upsample and
+    pool adjoints, both fused CE heads).  The kept run: profiles/r05_insitu_b16.txt.  The losses are NOT compared with the CPU
+    oracle here (a batch-16 oracle step needs 50 GB of host memory): tests/test_headline_gpu.py does that against the
+    reference's own batch-16 fixture."""
+    chk = _case(report, "pspnet101 c150 473^2 b16 SAMPLED [%s]" % arith, "psp", 101, 150, 473, 16, oracle_loss=False,
+                only=lambda kind, name: name is None or name.startswith(B16_SAMPLE))
+    assert sum(1 for r in chk.rows if r[2] == "wgrad-wino") >= 10
+    assert sum(1 for r in chk.rows if r[2].startswith("dgrad+bnr")) >= 20
+    assert any(r[0] == "stem" for r in chk.rows) and any(r[0] == "ce" for r in chk.rows)
 
 
 @pytest.mark.skipif(os.environ.get("SEMSEG_SKIP_BIG_INSITU") == "1", reason="big in-situ cases disabled")
