@@ -39,10 +39,14 @@ int semseg_psamask_backward(int psa_type, const float* grad_output, float* grad_
  *                        fp32, so the pieces carry all 24 mantissa bits; the product is rebuilt from the six leading
  *                        cross products ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm on v_mfma_f32_32x32x16_bf16
  *                        (each exact in fp32; the three dropped ones are below 2^-24 of the result) with fp32
- *                        accumulation.  Measured error at or below the fp32 instruction's in every parity test
- *                        (DESIGN.md section 8.4).  Kernel instances without a split form (generic tap walk, 64 x 64
- *                        weight-gradient tiles) compute exact fp32 products under either value: `arith` never makes
- *                        a launch LESS precise than SEMSEG_ARITH_BF16X3.
+ *                        accumulation.  Measured error, PER OP against fp64: at or below the fp32 instruction's (tests/
+ *                        test_ops_gpu.py, the in-situ tables of profiles/); at NETWORK level it is slightly above the exact path's
+ *                        everywhere and inside every bound (PSPNet-101 473^2: eval logits 3.4e-6 vs 2.1e-6 of max, cls.4.weight
+ *                        gradient 1.3e-4 vs 8.5e-5, 247 vs 217 argmax flips of 3.6 M pixels; profiles/r04_parity_report.txt).
+ *                        Kernel instances without a split form (the generic tap walk of kernel sizes other than 1x1 / 3x3, the
+ *                        PSA contraction) compute exact fp32 products under either value; the 64 x 64 weight-gradient tiles
+ *                        HAVE a split form since round 4 (conv_wgrad_kernel<64,64,MODE,3>) and run it under BF16X3:
+ *                        `arith` never makes a launch LESS precise than SEMSEG_ARITH_BF16X3.
  * Any other value: SEMSEG_EINVAL (-1).  No process-wide state is involved: concurrent launches on different streams /
  * host threads may use different values. */
 enum { SEMSEG_ARITH_F32 = 0, SEMSEG_ARITH_BF16X3 = 3 };
@@ -223,9 +227,10 @@ int semseg_bn_param_grads(double* sums, int nslot, float* dgamma, float* dbeta, 
  * (hipIpcMemHandle_t, 64 bytes) and maps every peer's (semseg_xchg_ipc_import); peer_bases = HOST array of the `world`
  * mapped base pointers in rank order (own buffer at [rank]).  allreduce: out[0:n] = sum over ranks of (sum over the nslot
  * replicas of in[nslot][n]), summed in rank order on every rank (bit-identical results); seq = 1, 2, ... must advance by
- * one per call, identically on every rank; n <= SEMSEG_XCHG_MAX_DOUBLES.  A rank whose peers do not arrive within 20 s sets
- * *err_dev = 1 and returns garbage in out (the caller checks err_dev).  OPT-IN path: verified with several processes on
- * one GPU only (round 4), RCCL stays the default exchange. */
+ * one per call, identically on every rank; n <= SEMSEG_XCHG_MAX_DOUBLES.  A rank whose peers do not arrive within timeout_ms
+ * (<= 0: 20 000) sets *err_dev = 1 and returns garbage in out (the caller checks err_dev); once *err_dev is set every later
+ * exchange gives up at once.  Verified with several processes on one GPU only: the host side takes this path after a start-up
+ * self-test among the real peers and uses RCCL otherwise (semseg_amd/syncbn_xchg.py). */
 #define SEMSEG_XCHG_MAX_DOUBLES 16384
 size_t semseg_xchg_buffer_bytes(int world);
 int semseg_xchg_alloc(int world, void** ptr);
@@ -234,7 +239,7 @@ int semseg_xchg_ipc_export(void* ptr, void* handle64);
 int semseg_xchg_ipc_import(const void* handle64, void** ptr);
 int semseg_xchg_ipc_close(void* ptr);
 int semseg_xchg_allreduce_f64(const double* in, int nslot, int n, double* out, void* const* peer_bases, int world, int rank,
-                              unsigned long long seq, int* err_dev, hipStream_t stream);
+                              unsigned long long seq, int* err_dev, int timeout_ms, hipStream_t stream);
 
 /* ---- spatial ops: MaxPool2d(3,2,1) model/resnet.py:115; AdaptiveAvgPool2d model/pspnet.py:14;
  * F.interpolate(bilinear, align_corners=True) model/pspnet.py:25,95,100; model/psanet.py:61,78,97. */
@@ -370,13 +375,50 @@ int semseg_intersection_and_union(const long long* pred, const long long* target
 /* Dropout2d(p) keep/scale mask, one value per (n, c) plane (model/pspnet.py:68,76): 1/(1-p) with probability 1-p,
  * else 0; counter-based generator keyed by (seed, offset, plane).  semseg_memset_zero: hipMemsetAsync on the stream. */
 int semseg_dropout2d_mask(float* mask, int n, float p, unsigned long long seed, unsigned long long offset,
-                          hipStream_t stream);
+                          const unsigned long long* offset_dev, hipStream_t stream);   /* offset_dev (optional): offset += *offset_dev, read on the device */
 int semseg_memset_zero(void* ptr, size_t bytes, hipStream_t stream);
 
 /* ---- torch.optim.SGD step (tool/train.py:140,276) over a flat range. */
 int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, float lr, const float* lr_dev,
                     float momentum, float weight_decay, float grad_scale, int first_step,
                     hipStream_t stream);
+
+/* ---- Step plan: launch sequencing below the C ABI (csrc/plan.hip).  The loop body of the reference's train step
+ * (tool/train.py:269-276: model(input, target), loss, zero_grad, backward, optimizer.step) is ~1 200 launches of the entry
+ * points above with arguments that do not change from step to step.  A host driver records them once — semseg_plan_append:
+ * entry point (semseg_plan_fn_id of its name) + one 64-bit slot per argument: pointers / integers / hipStream_t by value
+ * (integers sign-extended), float / double by bit pattern in the low 32 / all 64 bits — and replays them from C:
+ * semseg_plan_replay calls entries [first, last) in order and stops at the first non-zero return code (returned;
+ * semseg_plan_failed_entry names the entry).  semseg_plan_graph_capture captures the same replay into a hipGraph owned by the
+ * plan (returns its id >= 0; `origin` = the non-default stream the range starts and ends on, other streams joined through
+ * semseg_stream_wait_stream), semseg_plan_graph_launch launches it.  A range that contains a collective is replayed in
+ * segments around it.  Per-step values live in device memory: semseg_step_state_set writes {lr, lr_head} (read by
+ * semseg_sgd_step through lr_dev) and the dropout call offset (semseg_dropout2d_mask's offset_dev) on the stream.
+ * A driver accepts a record only when the NEXT step, recorded the same way, holds the same calls (semseg_plan_compare): a
+ * step whose launch sequence depends on anything but the recorded arguments is never replayed.
+ * semseg_plan_* entry points themselves cannot be recorded.  semseg_stream_wait_stream(waiter, signaller): work enqueued on
+ * `waiter` afterwards runs after the work enqueued on `signaller` so far (event record + wait; a graph edge under capture).
+ * semseg_host_probe: host-only, stores its arguments in host_out[0..5] and counts calls in host_out[6]; returns
+ * SEMSEG_EINVAL for a == -12345 (tests of the slot encoding on machines without a GPU). */
+int semseg_plan_create(void** plan);
+int semseg_plan_destroy(void* plan);
+int semseg_plan_fn_id(const char* name);
+int semseg_plan_fn_nargs(int fn_id);
+int semseg_plan_append(void* plan, int fn_id, int nargs, const unsigned long long* slots);
+int semseg_plan_size(void* plan);
+int semseg_plan_entry_fn(void* plan, int entry);
+int semseg_plan_set_slot(void* plan, int entry, int arg, unsigned long long bits);
+int semseg_plan_get_slot(void* plan, int entry, int arg, unsigned long long* bits);
+int semseg_plan_compare(void* plan_a, void* plan_b, int ignore_fn, int ignore_arg, int* where);   /* 0 equal; 1 differ at entry where[0], argument where[1] (-1: entry point / count); argument ignore_arg of entry point ignore_fn is not compared */
+int semseg_plan_replay(void* plan, int first, int last);
+int semseg_plan_failed_entry(void* plan);
+int semseg_plan_graph_capture(void* plan, int first, int last, hipStream_t origin);
+int semseg_plan_graph_launch(void* plan, int graph, hipStream_t stream);
+int semseg_plan_graph_nodes(void* plan, int graph);
+int semseg_stream_wait_stream(hipStream_t waiter, hipStream_t signaller);
+int semseg_step_state_set(float* lr_dev2, float lr, float lr_head, unsigned long long* drop_dev,
+                          unsigned long long drop_offset, hipStream_t stream);
+int semseg_host_probe(unsigned long long* host_out, int a, long long b, size_t c, float d, double e, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,34 +1,44 @@
-"""Host-side issue time of a train step against its GPU time: python scripts/host_issue_time.py [batch]
-After a device synchronisation the step is issued (t_issue = until tr.step returns) and drained (t_total)."""
-import os, sys, time
+"""Host-side issue time of a train step against its GPU time, for the three step drivers:
+  eager  Python sequences every launch through ctypes (rounds 1-4)
+  plan   recorded once, replayed by one semseg_plan_replay call (csrc/plan.hip)
+  graph  the same record captured into one hipGraph (semseg_plan_graph_launch)
+host ms = wall time of the python thread inside Trainer.step with an idle queue in front of it (synchronize before every
+step: nothing to wait for but the issue itself); device ms = back-to-back steps.   python scripts/host_issue_time.py [batch] [out.json]"""
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from semseg_amd.trainer import Trainer
 from model.pspnet import PSPNet
+from semseg_amd.trainer import Trainer
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-torch.manual_seed(0)
-m = PSPNet(layers=101, classes=150, zoom_factor=8, pretrained=False).cuda().train()
-tr = Trainer(m, base_lr=0.01, sync_bn=True)
-x = torch.randn(B, 3, 473, 473).cuda()
-y = torch.randint(0, 150, (B, 473, 473)).cuda()
-for _ in range(3):
-    tr.step(x, y, 0.01)
-iss, tot = [], []
-for _ in range(10):
+res = {"batch": B}
+for mode in ("eager", "plan", "graph"):
+    torch.manual_seed(0)
+    m = PSPNet(layers=101, classes=150, zoom_factor=8, pretrained=False).cuda().train()
+    tr = Trainer(m, base_lr=0.01, sync_bn=True)
+    tr.use_plan, tr.use_graph = mode != "eager", mode == "graph"
+    x = torch.randn(B, 3, 473, 473).cuda()
+    y = torch.randint(0, 150, (B, 473, 473)).cuda()
+    for _ in range(6):
+        tr.step(x, y, 0.01)
+    torch.cuda.synchronize()
+    host = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.step(x, y, 0.01)
+        host.append((time.perf_counter() - t0) * 1e3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tr.step(x, y, 0.01)
-    t1 = time.perf_counter()
+    for _ in range(10):
+        tr.step(x, y, 0.01)
     torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    iss.append((t1 - t0) * 1e3)
-    tot.append((t2 - t0) * 1e3)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(10):
-    tr.step(x, y, 0.01)
-torch.cuda.synchronize()
-back = (time.perf_counter() - t0) * 100
-print("batch %d: issue %.2f ms (min %.2f), issue+drain %.2f ms, back-to-back %.2f ms/step"
-      % (B, sum(iss) / len(iss), min(iss), sum(tot) / len(tot), back))
+    dev = (time.perf_counter() - t0) / 10 * 1e3
+    res[mode] = {"host_issue_ms": round(min(host), 3), "host_issue_ms_all": [round(h, 3) for h in host],
+                 "step_ms_back_to_back": round(dev, 3), "plan_log": tr.plan_log[-1:]}
+    print(mode, res[mode], flush=True)
+    del tr, m
+    torch.cuda.empty_cache()
+if len(sys.argv) > 2:
+    json.dump(res, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(res))

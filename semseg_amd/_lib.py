@@ -44,6 +44,8 @@ class _Lib:
     def __init__(self):
         self._dll = None
         self._fn = {}
+        self._argtypes = {}
+        self.recorder = None      # semseg_amd.plan.StepPlan while it records: every successful call is appended to it
 
     def load(self):
         if self._dll is None:
@@ -61,14 +63,22 @@ class _Lib:
                 f.restype = ret
                 f.argtypes = [a[0] for a in args]
                 self._fn[name] = f
+                self._argtypes[name] = f.argtypes
         return self
 
     def __getattr__(self, name):
         self.load()
         try:
-            return self._fn[name]
+            f = self._fn[name]
         except KeyError:
             raise AttributeError(name)
+        r = self.recorder
+        return f if r is None else r.wrap(name, f, self._argtypes[name])
+
+    def raw(self, name):
+        """The ctypes function itself, never the recording wrapper."""
+        self.load()
+        return self._fn[name]
 
 
 lib = _Lib()

@@ -24,6 +24,9 @@ namespace {
 
 
 constexpr int SB_BM = 256, SB_BN = 128, SB_THREADS = 512;
+#ifndef SB_NBUF
+#define SB_NBUF 2      // 1: the single-buffered K loop of rounds 3-4 (two barriers per K step; A/B builds only)
+#endif
 #ifndef EPI_WIDE
 #define EPI_WIDE 1     // 0: direct dword stores from the accumulator layout (the round-3 epilogue; A/B builds only)
 #endif
@@ -121,15 +124,19 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
   constexpr int RPP = SB_THREADS / K4;              // rows covered by one pass of the workgroup
   constexpr int A_PER = SB_BM / RPP, B_PER = SB_BN / RPP;
   static_assert(A_PER >= 1 && B_PER >= 1, "stage shape");
-  // one allocation: [NS][SB_BM * BK] A pieces, then [NS][SB_BN * BK] B pieces; the epilogue reuses it as per-wave slabs
+  // one allocation per stage: [NS][SB_BM * BK] A pieces, then [NS][SB_BN * BK] B pieces; the epilogue reuses it as per-wave slabs.
+  // NBUF = 2 (three pieces, BK 16: 2 x 36 KB, still two workgroups per CU in 160 KB): the pieces of stage kt + 1 are written into
+  // the other buffer while stage kt is being multiplied, ONE barrier per K step (round 5; the single-buffered loop had two, with
+  // the split + store phase of every wave of a workgroup sitting between them while no wave of it could multiply).
+  constexpr int NBUF = (NS == 3 && BK == 16) ? SB_NBUF : 1;
   constexpr int SLAB_LD = 36;                                           // floats per slab row (conflict-free ds_read_b128)
   constexpr int STAGE_BYTES = NS * (SB_BM + SB_BN) * BK * 2;
   constexpr int SLAB_BYTES = (SB_THREADS / 64) * 32 * SLAB_LD * 4;
   constexpr int RED2_BYTES = EPI == 2 ? 4 * SB_BN * 2 * 8 : 0;          // fp64 column sums of the fused reduction: [4 (wm)][SB_BN][2]
   constexpr int EPI_BYTES = SLAB_BYTES + RED2_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
-  __bf16 (*sA)[SB_BM * BK] = reinterpret_cast<__bf16 (*)[SB_BM * BK]>(smem_raw);
-  __bf16 (*sB)[SB_BN * BK] = reinterpret_cast<__bf16 (*)[SB_BN * BK]>(smem_raw + NS * SB_BM * BK * 2);
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[NBUF * STAGE_BYTES > EPI_BYTES ? NBUF * STAGE_BYTES : EPI_BYTES];
+  auto sA = [&](int buf, int c) { return reinterpret_cast<__bf16*>(smem_raw + buf * STAGE_BYTES) + c * (SB_BM * BK); };
+  auto sB = [&](int buf, int c) { return reinterpret_cast<__bf16*>(smem_raw + buf * STAGE_BYTES + NS * SB_BM * BK * 2) + c * (SB_BN * BK); };
 
   int t = xcd_remap(blockIdx.x, p.total);
   const int tn = t % p.tiles_n; t /= p.tiles_n;     // column tiles of one row panel are XCD neighbours
@@ -152,10 +159,29 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
   for (int j = 0; j < B_PER; ++j) gb[j] = Bt + (size_t)(n0 + r0 + j * RPP) * p.K + kq * 4;   // panel rows are padded
 
   f32x4 ra[A_PER], rb[B_PER];
+  auto stage_load = [&](int kt) {
 #pragma unroll
-  for (int j = 0; j < A_PER; ++j) ra[j] = *(const f32x4*)ga[j];
+    for (int j = 0; j < A_PER; ++j) ra[j] = *(const f32x4*)(ga[j] + (size_t)kt * BK);
 #pragma unroll
-  for (int j = 0; j < B_PER; ++j) rb[j] = *(const f32x4*)gb[j];
+    for (int j = 0; j < B_PER; ++j) rb[j] = *(const f32x4*)(gb[j] + (size_t)kt * BK);
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+      bf16x4 pc[NS];
+      split4<NS>(ra[j], pc);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) *(bf16x4*)&sA(buf, c)[off(r0 + j * RPP, kq >> 1) + (kq & 1) * 4] = pc[c];
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+      bf16x4 pc[NS];
+      split4<NS>(rb[j], pc);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) *(bf16x4*)&sB(buf, c)[off(r0 + j * RPP, kq >> 1) + (kq & 1) * 4] = pc[c];
+    }
+  };
+  stage_load(0);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -166,29 +192,7 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int frow = lane & 31, fk8 = lane >> 5;
-  const int KT = p.K / BK;
-  for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-    for (int j = 0; j < A_PER; ++j) {
-      bf16x4 pc[NS];
-      split4<NS>(ra[j], pc);
-#pragma unroll
-      for (int c = 0; c < NS; ++c) *(bf16x4*)&sA[c][off(r0 + j * RPP, kq >> 1) + (kq & 1) * 4] = pc[c];
-    }
-#pragma unroll
-    for (int j = 0; j < B_PER; ++j) {
-      bf16x4 pc[NS];
-      split4<NS>(rb[j], pc);
-#pragma unroll
-      for (int c = 0; c < NS; ++c) *(bf16x4*)&sB[c][off(r0 + j * RPP, kq >> 1) + (kq & 1) * 4] = pc[c];
-    }
-    __syncthreads();
-    if (kt + 1 < KT) {
-#pragma unroll
-      for (int j = 0; j < A_PER; ++j) ra[j] = *(const f32x4*)(ga[j] + (size_t)(kt + 1) * BK);
-#pragma unroll
-      for (int j = 0; j < B_PER; ++j) rb[j] = *(const f32x4*)(gb[j] + (size_t)(kt + 1) * BK);
-    }
+  auto multiply = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 fb[2][NS];
@@ -196,12 +200,12 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int c = 0; c < NS; ++c)
-          fb[j][c] = *(const bf16x8*)&sB[c][off(wn * 64 + j * 32 + frow, ks * 2 + fk8)];
+          fb[j][c] = *(const bf16x8*)&sB(buf, c)[off(wn * 64 + j * 32 + frow, ks * 2 + fk8)];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         bf16x8 fa[NS];
 #pragma unroll
-        for (int c = 0; c < NS; ++c) fa[c] = *(const bf16x8*)&sA[c][off(wm * 64 + i * 32 + frow, ks * 2 + fk8)];
+        for (int c = 0; c < NS; ++c) fa[c] = *(const bf16x8*)&sA(buf, c)[off(wm * 64 + i * 32 + frow, ks * 2 + fk8)];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           // small terms first, the leading product last
@@ -216,6 +220,30 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
         }
       }
     }
+  };
+  const int KT = p.K / BK;
+  if constexpr (NBUF == 1) {
+    for (int kt = 0; kt < KT; ++kt) {
+      stage_store(0);
+      __syncthreads();
+      if (kt + 1 < KT) stage_load(kt + 1);
+      multiply(0);
+      __syncthreads();
+    }
+  } else {
+    stage_store(0);
+    __syncthreads();
+    if (KT > 1) stage_load(1);
+    // straight-line body (the last step is peeled, the look-ahead load is clamped instead of branched around) so that the
+    // compiler can interleave the split + store of stage kt + 1 with the matrix-core instructions of stage kt
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+      const int cur = kt & 1;
+      stage_store(cur ^ 1);      // buffer cur ^ 1 was last read in step kt - 1, which every wave left through the barrier below
+      stage_load(min(kt + 2, KT - 1));
+      multiply(cur);
+      __syncthreads();
+    }
+    multiply((KT - 1) & 1);
     __syncthreads();
   }
 

@@ -32,9 +32,11 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const f
 // ones by 1/(1-p)): one value per plane from a counter-based generator (splitmix64 of seed, call offset and plane
 // index) — same distribution as torch's, not the same bit stream (semantics, not bit patterns).
 __global__ void dropout2d_mask_kernel(float* __restrict__ mask, int n, float keep, float scale,
-                                      unsigned long long seed, unsigned long long offset) {
+                                      unsigned long long seed, unsigned long long offset,
+                                      const unsigned long long* __restrict__ offset_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (offset_dev) offset += offset_dev[0];      // the per-step part of the call counter of a replayed step (plan.hip)
   unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (offset * 0x100000000ull + (unsigned long long)i + 1ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -45,9 +47,9 @@ __global__ void dropout2d_mask_kernel(float* __restrict__ mask, int n, float kee
 }  // namespace
 
 extern "C" int semseg_dropout2d_mask(float* mask, int n, float p, unsigned long long seed, unsigned long long offset,
-                                     hipStream_t stream) {
+                                     const unsigned long long* offset_dev, hipStream_t stream) {
   if (!mask || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return SEMSEG_EINVAL;
-  dropout2d_mask_kernel<<<(n + 255) / 256, 256, 0, stream>>>(mask, n, 1.f - p, 1.f / (1.f - p), seed, offset);
+  dropout2d_mask_kernel<<<(n + 255) / 256, 256, 0, stream>>>(mask, n, 1.f - p, 1.f / (1.f - p), seed, offset, offset_dev);
   return semseg_launch_status();
 }
 

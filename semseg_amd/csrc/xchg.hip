@@ -18,8 +18,10 @@
 // then reads the slots with system-scope loads.  Every spin is bounded: after 20 s the kernel gives up, sets *err and
 // finishes with whatever it has — the host raises (SyncExchange.check()).
 //
-// STATUS (round 4): exercised with two processes on ONE GPU (tests/test_dist_gpu.py, both ranks' buffers in the same HBM,
-// IPC-mapped across processes); it has NOT run across xGMI — opt-in (SEMSEG_SYNCBN_XCHG=1), RCCL stays the default.
+// STATUS (round 5): exercised with two and four processes on ONE GPU (tests/test_dist_gpu.py, the ranks' buffers in the same
+// HBM, IPC-mapped across processes); it has NOT run across xGMI.  The host side (semseg_amd/syncbn_xchg.py) therefore takes it
+// only after a start-up self-test among the real peers — 64 exchanges of known vectors with a 2 s bound, every rank's result
+// checked, the verdict agreed by all ranks — and falls back to RCCL otherwise (SEMSEG_SYNCBN_XCHG=auto, the default).
 #include <cstring>
 
 #include "common.h"
@@ -36,6 +38,7 @@ struct XchgArgs {
   double* out;                    // [n]
   int* err;
   unsigned long long seq;
+  unsigned long long limit_ticks;   // bound of the flag wait in ticks of the 100 MHz constant clock
   int world, rank, nslot, n;
 };
 
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(const XchgArgs p) 
     // launched when its python thread gets there: first-use code-object loads, a rank whose process was scheduled late — a
     // 1 s bound fired once in the two-processes-on-one-GPU test), so it is 20 s; an exchange that already failed in this
     // process makes the following ones give up at once instead of waiting 20 s each.
-    const unsigned long long t0 = wall_clock64(), limit = *p.err ? 0ull : 2000000000ull;
+    const unsigned long long t0 = wall_clock64(), limit = *p.err ? 0ull : p.limit_ticks;
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.seq) {
       __builtin_amdgcn_s_sleep(16);
       if (wall_clock64() - t0 > limit) {      // a peer never arrived (crashed, different call sequence, not co-resident)
@@ -150,7 +153,7 @@ int semseg_xchg_ipc_import(const void* handle64, void** ptr) {
 int semseg_xchg_ipc_close(void* ptr) { return (!ptr || hipIpcCloseMemHandle(ptr) == hipSuccess) ? SEMSEG_OK : SEMSEG_ELAUNCH; }
 
 int semseg_xchg_allreduce_f64(const double* in, int nslot, int n, double* out, void* const* peer_bases, int world, int rank,
-                              unsigned long long seq, int* err_dev, hipStream_t stream) {
+                              unsigned long long seq, int* err_dev, int timeout_ms, hipStream_t stream) {
   if (!in || !out || !peer_bases || !err_dev || world < 1 || world > XCHG_MAX_WORLD || rank < 0 || rank >= world ||
       nslot < 1 || n < 1 || n > XCHG_MAX || seq == 0)
     return SEMSEG_EINVAL;
@@ -158,7 +161,8 @@ int semseg_xchg_allreduce_f64(const double* in, int nslot, int n, double* out, v
   for (int q = 0; q < XCHG_MAX_WORLD; ++q) a.peer[q] = q < world ? static_cast<double*>(peer_bases[q]) : nullptr;
   for (int q = 0; q < world; ++q)
     if (!a.peer[q]) return SEMSEG_EINVAL;
-  a.in = in; a.out = out; a.err = err_dev; a.seq = seq; a.world = world; a.rank = rank; a.nslot = nslot; a.n = n;
+  a.in = in; a.out = out; a.err = err_dev; a.seq = seq;
+  a.limit_ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 20000) * 100000ull; a.world = world; a.rank = rank; a.nslot = nslot; a.n = n;
   xchg_allreduce_kernel<<<1, 1024, 0, stream>>>(a);
   return semseg_launch_status();
 }

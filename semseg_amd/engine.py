@@ -243,6 +243,9 @@ class BNL:
 # ms for an identical second one).  Engines of one process never run concurrently, so sharing is safe.
 _SHARED = {}
 MAX_SCRATCH_ARENAS = 4
+# Bumped whenever a process-wide arena is replaced or released: a recorded step plan (semseg_amd/plan.py) holds the addresses
+# of the arenas it saw and is discarded (re-recorded) when this moved since.
+ARENA_GEN = [0]
 
 
 def _shared(device, name, make):
@@ -329,6 +332,10 @@ class Engine:
         self._mod_ids = tuple(id(m) for m in model.modules())
         self._labels_checked = False
         self._drop_calls = 0
+        # per-step part of the dropout call counter as the DEVICE sees it (semseg_dropout2d_mask's offset_dev): zero on the
+        # eager path, advanced by Trainer before every replay of a recorded step (semseg_step_state_set)
+        self.drop_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.recorder = None   # semseg_amd.plan.StepPlan while Trainer records a step of this engine
         self.tape_hook = None  # callable(TapeOp) that must call op.fn(); set by tests only
         self._groups = {}
         self.syncbn_collectives_per_step = 0   # SyncBN all-reduces issued by the last forward + backward
@@ -532,7 +539,8 @@ class Engine:
             return out
         rs = cl.R * cl.S if cl.R * cl.S in (1, 9) else 0
         ar = cl.arith if rs else ops.ARITH_F32       # the generic tap walk has no split instance
-        tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld, ar)
+        tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld, ar,
+                               plain=fold is None and not (bias and m.bias is not None))
         fam = ("gemm_rows_bf16split_kernel<3,16,1> (bf16x3, 1x1 conv + statistics)" if tile == ops.TILE_SPLIT_GEMM else
                "conv_igemm_kernel<%d,%d,false,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)))
         ev = self._t0(fam, 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
@@ -594,7 +602,7 @@ class Engine:
         side = self.side_wgrad and (self.side_all or y.M * cl.Co < 512 * 128 * 128)
         if side:
             st, scr = self._side_stream()
-            st.wait_stream(torch.cuda.current_stream())
+            ops.stream_wait(st, torch.cuda.current_stream())
             self._side_used = True      # before the block: _wgrad may hand a gradient bucket to the communicator
             with torch.cuda.stream(st):
                 self._wgrad(x, y, cl, m, scr)
@@ -613,9 +621,10 @@ class Engine:
                     all(yk.ld % 4 == 0 for yk, _ in bs["bns"]))
             rs = cl.R * cl.S if cl.R * cl.S in (1, 9) else 0
             ar = cl.arith if rs else ops.ARITH_F32
-            tile = ops.chosen_tile("dgrad", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, y.ld, x.ld, ar)
+            tile = ops.chosen_tile("dgrad", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, y.ld, x.ld, ar,
+                                   plain=not (fuse and len(bs["bns"]) > 1))
             fam = ("gemm_rows_bf16split_kernel<3,16,2> (bf16x3, 1x1 data gradient + fused reduction)"
-                   if tile == ops.TILE_SPLIT_GEMM and not (fuse and len(bs["bns"]) > 1) else
+                   if tile == ops.TILE_SPLIT_GEMM else
                    "conv_igemm_kernel<%d,%d,true,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)))
             ev = self._t0(fam, flops)
             if fuse:
@@ -640,6 +649,7 @@ class Engine:
         if t is None or t.numel() < floats:
             if t is not None:
                 torch.cuda.synchronize(self.device)     # a larger shape arrived: nothing may still read the old arena
+                ARENA_GEN[0] += 1
             t = _SHARED[key] = (torch.zeros if name == "Yh" else torch.empty)(floats, dtype=F32, device=self.device)
         return t
 
@@ -696,7 +706,7 @@ class Engine:
 
         if self.side_wgrad:
             st, scr = self._side_stream()
-            st.wait_stream(torch.cuda.current_stream())
+            ops.stream_wait(st, torch.cuda.current_stream())
             self._side_used = True
             with torch.cuda.stream(st):
                 wgrad(scr)
@@ -752,6 +762,7 @@ class Engine:
         if len(lru) >= MAX_SCRATCH_ARENAS:
             torch.cuda.synchronize(self.device)
             lru.pop(0)
+            ARENA_GEN[0] += 1
         t = torch.empty(64 * 1024 * 1024, dtype=F32, device=self.device)
         lru.append((st.cuda_stream, t))
         return t
@@ -790,20 +801,33 @@ class Engine:
         cur = torch.cuda.current_stream()
         for st in self._sides + [self._main]:
             if st != cur:
-                cur.wait_stream(st)
+                ops.stream_wait(cur, st)
 
     def _syncing(self):
         return (self.sync_bn or self.force_sync_bn) and self.dist_on
 
     def _all_reduce(self, t):
-        """One SyncBN exchange: RCCL by default; with SEMSEG_SYNCBN_XCHG=1 the peer-memory exchange kernel
-        (semseg_amd/syncbn_xchg.py: one launch, no c10d call; opt-in until it has run across xGMI)."""
+        """One SyncBN exchange: the peer-memory exchange kernel (semseg_amd/syncbn_xchg.py: one launch, no c10d call) when
+        it passed its start-up self-test among the job's ranks or is forced, RCCL otherwise."""
         from . import syncbn_xchg
-        if syncbn_xchg.enabled():
-            syncbn_xchg.get(self.device).all_reduce(t)
-        else:
-            dist.all_reduce(t)
+        xc = syncbn_xchg.active(self.device)
+
+        def exchange():
+            if xc is not None:
+                xc.all_reduce(t)
+            else:
+                dist.all_reduce(t)
+        self.host_op(exchange)
         self.syncbn_collectives_per_step += 1
+
+    def host_op(self, fn):
+        """Runs a host-side operation of the step (a torch.distributed collective).  While a step plan records this engine's
+        launches (semseg_amd/plan.py) the operation also becomes a segment boundary of the plan and is re-issued, on the stream
+        that is current now, by every replay."""
+        if self.recorder is None:
+            fn()
+        else:
+            self.recorder.py_op(fn)
 
     def _group(self, bls):
         key = tuple(id(b) for b in bls)
@@ -1102,7 +1126,7 @@ class Engine:
             dm = self.buf((x.N, conv_a.weight.shape[0]), tag="dropmask")
             # seeded from torch's generator state (torch.manual_seed reproduces a run), advanced per call
             self._drop_calls += 1
-            ops.dropout2d_mask(dm, drop.p, torch.initial_seed(), self._drop_calls)
+            ops.dropout2d_mask(dm, drop.p, torch.initial_seed(), self._drop_calls, self.drop_dev)
         a = self.conv_bn(x, conv_a, bn_a, dropmask=dm)
         ncls = conv_b.weight.shape[0]
         out = self.act(x.N, x.H, x.W, ncls, ld=ops.roundup(ncls, 128), tag="scores" + tag)
@@ -1118,7 +1142,7 @@ class Engine:
             if drop.training and drop.p > 0:
                 dm = self.buf((x.N, conv_a.weight.shape[0]), tag="dropmask")
                 self._drop_calls += 1
-                ops.dropout2d_mask(dm, drop.p, torch.initial_seed(), self._drop_calls)
+                ops.dropout2d_mask(dm, drop.p, torch.initial_seed(), self._drop_calls, self.drop_dev)
             hs.append((self.conv(x, conv_a, stats=self._st(bn_a)), dm))
         bns = [self.model.cls[1], self.model.aux[1]]
         cnts = self.bn_prepare_group([(bm, yh.M) for bm, (yh, _) in zip(bns, hs)])
@@ -1261,10 +1285,10 @@ class Engine:
             if self._hi is None:
                 self._hi = _shared(self.device, "hipri", lambda: torch.cuda.Stream(device=self.device, priority=-1))
             cur = torch.cuda.current_stream()
-            self._hi.wait_stream(cur)
+            ops.stream_wait(self._hi, cur)
             with torch.cuda.stream(self._hi):
                 self._backward_chain(gmain, gaux)
-            cur.wait_stream(self._hi)
+            ops.stream_wait(cur, self._hi)
         else:
             self._backward_chain(gmain, gaux)
 
@@ -1276,7 +1300,7 @@ class Engine:
             self._run(op)
         if self._side_used:
             for st in self._sides:
-                torch.cuda.current_stream().wait_stream(st)       # join the weight-gradient stream(s)
+                ops.stream_wait(torch.cuda.current_stream(), st)       # join the weight-gradient stream(s)
             self._side_used = False
 
     def _reset_grad_flags(self):

@@ -101,8 +101,13 @@ def load_tile_table(path=TILE_TABLE_PATH):
         return {k: int(v) for k, v in _json.load(f)["tiles"].items()}
 
 
+TILE_RUNNER_UP = {}     # key -> best measured implicit-GEMM tile of a shape whose table entry is 2128
+
+
 def _load_tables():
-    """Both committed tables in one dict; a code whose column width exceeds what the packed panels of that layer are padded
+    """Both committed tables in one dict (and, for every shape that runs the 256 x 128 GEMM kernel, the best measured
+    implicit-GEMM tile beside it: what a launch of that shape takes when it is NOT a plain row GEMM — an eval forward with
+    the BatchNorm / ReLU / residual folded in, a bias, two fused BatchNorm layers on the data gradient); a code whose column width exceeds what the packed panels of that layer are padded
     for (PackedConv: 64 columns for layers with fewer than 128 output columns) would make the kernel read past the
     panel, so such an entry is dropped here and the shape runs its default."""
     out = {}
@@ -115,7 +120,24 @@ def _load_tables():
             if v == TILE_SPLIT_GEMM and not (k.endswith("|sp") and _split_gemm_eligible(k)):
                 continue
             out[k] = v
+        try:
+            with open(path) as f:
+                times = _json.load(f).get("ms_per_tile_code", {})
+        except OSError:
+            times = {}
+        for k, v in out.items():
+            if v == TILE_SPLIT_GEMM and k in times:
+                ig = {int(c): ms for c, ms in times[k].items() if int(c) in TILE_CODES}
+                if ig:
+                    TILE_RUNNER_UP[k] = min(ig, key=ig.get)
     return out
+
+
+def plain_tile(tile, key, dflt, plain):
+    """Tile code 2128 is for plain row GEMMs; anything else of that shape runs its best measured implicit-GEMM tile."""
+    if tile != TILE_SPLIT_GEMM or plain:
+        return tile
+    return TILE_RUNNER_UP.get(key, dflt)
 
 
 def _split_gemm_eligible(key):
@@ -199,20 +221,23 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
                        lambda t, out: lib.semseg_conv_fwd(
                            _p(x), ldx, _p(pk.w_fwd), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
                            pad, dil, None, None, 0, None, 0, _p(tstats), NSLOT, t, arith, *_scr(scratch), _stream()), arith)
+    tile = plain_tile(tile, tile_key("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil) + "|sp", pk.tile_fwd,
+                      bias is None and scale is None and not relu and add is None)
     _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
                             pk.R, pk.S, stride, pad, dil, _p(bias), _p(scale), int(relu), _p(add), ldadd,
                             _p(stats), nslot, tile, arith, *_scr(scratch), _stream()), "conv_fwd")
     return Ho, Wo
 
 
-def chosen_tile(kind, pk, N, H, W, stride, pad, dil, ld_in, ld_out, arith=ARITH_F32):
-    """Tile width the (already measured) shape runs with; kind "fwd" | "dgrad".  For kernel-family labels."""
+def chosen_tile(kind, pk, N, H, W, stride, pad, dil, ld_in, ld_out, arith=ARITH_F32, plain=True):
+    """Tile width the (already measured) shape runs with; kind "fwd" | "dgrad"; plain = the launch is a plain row GEMM (nothing
+    folded into a forward's epilogue, at most one fused BatchNorm layer on a data gradient).  For kernel-family labels."""
     dflt = pk.tile_fwd if kind == "fwd" else pk.tile_dgrad
     key = tile_key(kind, N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil) + ("|sp" if arith == ARITH_BF16X3 else "")
     if _FORCE_SPLIT_GEMM and dflt == 128 and arith == ARITH_BF16X3 and _split_gemm_eligible(key):
-        return TILE_SPLIT_GEMM
+        return plain_tile(TILE_SPLIT_GEMM, key, dflt, plain)
     t = TILE_CHOICE.get(key, dflt)
-    return t if (dflt == 128 or t % 1000 == 64) else dflt
+    return plain_tile(t if (dflt == 128 or t % 1000 == 64) else dflt, key, dflt, plain)
 
 
 def _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch, arith=ARITH_F32):
@@ -258,7 +283,8 @@ def conv_dgrad_bnreduce(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, act, 
     Wo = conv_out(W, pk.S, stride, pad, dil)
     b0 = bns[0]
     b1 = bns[1] if len(bns) > 1 else (None, 0, None, None, None)
-    tile = _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch, arith)
+    tile = plain_tile(_dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch, arith),
+                      tile_key("dgrad", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil) + "|sp", pk.tile_dgrad, len(bns) <= 1)
     _ck(lib.semseg_conv_dgrad_bnreduce(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R,
                                        pk.S, stride, pad, dil, _p(add), ldadd, tile, len(bns), _p(act), ldact,
                                        _p(relu_bits), 0 if relu_bits is None else relu_bits.shape[-1],
@@ -503,9 +529,15 @@ def ce_head_bwd(scores, ld, label, lse, acc2, grad_loss, grad_mul, dscores, lddz
                                ignore_index, *_scr(scratch), _stream()), "ce_head_bwd")
 
 
-def dropout2d_mask(mask, p, seed, offset):
+def dropout2d_mask(mask, p, seed, offset, offset_dev=None):
+    """offset_dev: optional device uint64 added to `offset` on the device (the per-step counter of a replayed step plan)."""
     _ck(lib.semseg_dropout2d_mask(_p(mask), mask.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset),
-                                  _stream()), "dropout2d_mask")
+                                  _p(offset_dev), _stream()), "dropout2d_mask")
+
+
+def stream_wait(waiter, signaller):
+    """torch.cuda.Stream.wait_stream through the C ABI (semseg_stream_wait_stream), so that a recorded step plan holds it."""
+    _ck(lib.semseg_stream_wait_stream(waiter.cuda_stream, signaller.cuda_stream), "stream_wait_stream")
 
 
 def zero_(t):

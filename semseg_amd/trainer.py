@@ -14,8 +14,19 @@ import torch
 import torch.distributed as dist
 
 
+from . import engine as _engine
 from . import ops
+from ._lib import lib
 from .engine import Engine
+from .plan import PlanError, StepPlan
+
+# Step plan (semseg_amd/plan.py, csrc/plan.hip): after EAGER_STEPS eager steps of an engine the next TWO are recorded (they run
+# launch by launch, as before) and, when both records hold the same calls with the same arguments, every later step is
+# replayed from C.  SEMSEG_STEP_PLAN=0: every step is sequenced by Python, launch by launch (rounds 1-4).
+# SEMSEG_STEP_GRAPH=1: a recorded single-GPU step is additionally captured into one hipGraph.
+STEP_PLAN = os.environ.get("SEMSEG_STEP_PLAN", "1") != "0"
+STEP_GRAPH = os.environ.get("SEMSEG_STEP_GRAPH", "0") == "1"
+EAGER_STEPS = 2
 
 
 def poly_learning_rate(base_lr, curr_iter, max_iter, power=0.9):
@@ -41,6 +52,9 @@ class Trainer:
         self.bucket_elems = bucket_mb * 1024 * 1024 // 4
         self.grad_group = dist.new_group() if self.dist_on else None
         self.timers = None
+        self.use_plan, self.use_graph = STEP_PLAN, STEP_GRAPH
+        self._step_state = torch.zeros(2, dtype=torch.float32, device=self.device)    # {lr, lr of the heads}: semseg_sgd_step's lr_dev
+        self.plan_log = []        # what happened to every recording attempt (tests, bench)
 
     # parameters -> one flat buffer (offsets 16-byte aligned, same layout as Engine.flat_grad)
     def _flatten(self):
@@ -73,6 +87,12 @@ class Trainer:
         if e is None:
             e = Engine(self.model, x.shape[0], x.shape[2], x.shape[3], True, self.model.kind)
             e.force_sync_bn = self.sync_bn and self.dist_on
+            if self.use_graph and os.environ.get("SEMSEG_GRAPH_KEEP_HIPRI") != "1":
+                # one level of forked streams inside a capture: the weight-gradient stream forks from the stream the step runs
+                # on.  (With the data-gradient chain on a second, high-priority stream the side stream is a fork of a fork, and
+                # hipStreamEndCapture of ROCm 7.0 crashes on the record — scripts/graph_debug.py; stream priorities mean
+                # nothing inside a graph anyway.)
+                e.hipri_main = False
             assert e.flat_grad.numel() == self.total
             if self.dist_on:
                 self._make_buckets(e)
@@ -109,7 +129,8 @@ class Trainer:
                 lo, hi, _ = e._buckets[bi]
                 # the bucket's gradients come from BOTH the main and the side stream, whichever issues this
                 e.order_after_all_producers()
-                e._works.append(dist.all_reduce(e.flat_grad[lo:hi], group=self.grad_group, async_op=True))
+                view = e.flat_grad[lo:hi]
+                e.host_op(lambda view=view: e._works.append(dist.all_reduce(view, group=self.grad_group, async_op=True)))
 
     # ------------------------------------------------------------------ one optimisation step
     def step(self, x, y, lr=None):
@@ -124,6 +145,23 @@ class Trainer:
         e = self.engine(x)
         if e.params_stale():
             raise RuntimeError("the module tree changed after the Trainer built its engine; build a new Trainer")
+        if not (self.use_plan and e.ktimer is None and e.tape_hook is None and not getattr(e, "_plan_off", False)):
+            if getattr(e, "_plan_replays", 0):
+                self._set_step_state(e, lr, 0)      # the device part of the dropout counter belongs to replayed steps only
+            return self._step_eager(e, x, y, lr)
+        # planned steps (the eager ones before the recording included) run on one stream of their own: a recorded stream handle
+        # must mean the same stream at every replay, and a graph cannot be captured on the default stream
+        cur = torch.cuda.current_stream()
+        if os.environ.get("SEMSEG_PLAN_OWN_STREAM", "1") == "0" and not self.use_graph:      # A/B only
+            return self._step_planned(e, x, y, lr, cur)
+        st = _engine._shared(self.device, "plan_stream", lambda: torch.cuda.Stream(device=self.device))
+        ops.stream_wait(st, cur)
+        with torch.cuda.stream(st):
+            out = self._step_planned(e, x, y, lr, st)
+        ops.stream_wait(cur, st)
+        return out
+
+    def _step_eager(self, e, x, y, lr, lr_dev=None):
         pred, main_loss, aux_loss = e.forward_train(x, y, self.ignore_index)
         if self.dist_on:
             e._pending = [len(ps) for _, _, ps in e._buckets]
@@ -131,18 +169,123 @@ class Trainer:
         e.backward(self.g_main, self.g_aux)
         if self.dist_on:
             assert all(c == 0 for c in e._pending), "a gradient bucket never completed"
-            for w in e._works:
-                w.wait()
+            e.host_op(lambda: [w.wait() for w in e._works])
         first = self.steps == 0
         gs = 1.0 / self.world
-        ops.sgd_step(self.flat_w, e.flat_grad, self.flat_m, self.split, lr, self.momentum, self.wd, gs, first)
+        # a recorded step reads both learning rates from device memory (semseg_step_state_set); the by-value argument is then
+        # unused and kept at 0 so that two records of consecutive steps of a schedule hold the same calls
+        ops.sgd_step(self.flat_w, e.flat_grad, self.flat_m, self.split, lr if lr_dev is None else 0.0, self.momentum, self.wd,
+                     gs, first, lr_dev=None if lr_dev is None else lr_dev[0:1])
         n2 = self.total - self.split
         ops.sgd_step(self.flat_w[self.split:], e.flat_grad[self.split:], self.flat_m[self.split:], n2,
-                     lr * 10.0, self.momentum, self.wd, gs, first)
+                     lr * 10.0 if lr_dev is None else 0.0, self.momentum, self.wd, gs, first,
+                     lr_dev=None if lr_dev is None else lr_dev[1:2])
         self.steps += 1
         # label counts of earlier steps that have reached the host by now (non-blocking; see Engine.LabelWatch)
         e._label_watch().poll(self.model.cls[4].weight.shape[0])
+        self._watch_exchange()
         return pred, main_loss, aux_loss
+
+    def _watch_exchange(self, wait=False):
+        """A SyncBN peer-memory exchange that timed out raises at most RING steps later (non-blocking poll of its error flag
+        through a pinned ring, like the label counts), or here with wait=True."""
+        if not self.dist_on:
+            return
+        from . import syncbn_xchg
+        xc = syncbn_xchg.DECISION.get(self.device.index, (None,))[0]
+        if xc is not None:
+            xc.poll(wait)
+            if not wait:
+                xc.watch()
+
+    # ------------------------------------------------------------------ step plan: record once, replay from C
+    def _set_step_state(self, e, lr, drop_offset):
+        ops._ck(lib.raw("semseg_step_state_set")(self._step_state.data_ptr(), float(lr), float(lr) * 10.0,
+                                                 e.drop_dev.data_ptr(), int(drop_offset), ops._stream()), "step_state_set")
+
+    def _step_planned(self, e, x, y, lr, st):
+        plan = getattr(e, "_plan", None)
+        if plan is not None and e._plan_gen != _engine.ARENA_GEN[0]:
+            plan = e._plan = None             # a process-wide arena the plan points into was replaced: record again
+            self.plan_log.append("discarded: arena generation moved")
+        if plan is not None:
+            e._plan_x.copy_(x)
+            e._plan_y.copy_(y)
+            k = e._plan_replays + 1
+            self._set_step_state(e, lr, k * e._plan_drops)
+            e._drop_calls += e._plan_drops
+            if self.dist_on:
+                e._works = []
+            e.model.__dict__["_hip_bn_epoch"] = e.model.__dict__.get("_hip_bn_epoch", 0) + 1
+            ncls = self.model.cls[4].weight.shape[0]
+            e._label_watch().poll(ncls)
+            plan.replay()
+            e._label_watch().watch(e._rec_main["acc"])
+            self._watch_exchange()
+            e._plan_replays = k
+            self.steps += 1
+            return e._plan_out
+        n = getattr(e, "_plan_eager", 0)
+        if n < EAGER_STEPS or self.steps == 0:
+            e._plan_eager = n + 1
+            self._set_step_state(e, lr, 0)
+            return self._step_eager(e, x, y, lr)
+        return self._record(e, x, y, lr, st)
+
+    def _record(self, e, x, y, lr, st):
+        if getattr(e, "_plan_x", None) is None:
+            e._plan_x = torch.empty_like(x, memory_format=torch.contiguous_format)
+            e._plan_y = torch.empty_like(y, memory_format=torch.contiguous_format)
+        e._plan_x.copy_(x)
+        e._plan_y.copy_(y)
+        self._set_step_state(e, lr, 0)
+        plan = StepPlan()
+        drops0 = e._drop_calls
+        allocs0 = torch.cuda.memory_stats(self.device).get("allocation.all.allocated", 0)
+        e.recorder = plan
+        plan.begin()
+        try:
+            out = self._step_eager(e, e._plan_x, e._plan_y, lr, lr_dev=self._step_state)
+        finally:
+            why = plan.end()          # a call that cannot be replayed does not stop the step: it only invalidates the record
+            e.recorder = None
+        if why is None and torch.cuda.memory_stats(self.device).get("allocation.all.allocated", 0) != allocs0:
+            why = "device memory was allocated while the step was recorded (a buffer address in the plan may be temporary)"
+        if why is not None:
+            e._plan_tries = getattr(e, "_plan_tries", 0) + 1
+            self.plan_log.append("recording failed: " + why)
+            if e._plan_tries >= 3:
+                e._plan_off = True
+                import warnings
+                warnings.warn("semseg_amd.Trainer: the step could not be recorded (%s); it stays on the launch-by-launch path" % why)
+            return out
+        e._plan_drops = e._drop_calls - drops0
+        prev = getattr(e, "_plan_candidate", None)
+        if prev is None or prev[1] != _engine.ARENA_GEN[0]:
+            e._plan_candidate = (plan, _engine.ARENA_GEN[0])     # accepted when the next step records the same calls
+            self.plan_log.append("candidate: %d launches, %d host operations" % (plan.launches(), plan.host_ops()))
+            return out
+        e._plan_candidate = None
+        diff = prev[0].same_as(plan, ignore=("semseg_dropout2d_mask", 4))
+        if diff is not None:
+            e._plan_tries = getattr(e, "_plan_tries", 0) + 1
+            self.plan_log.append("recording failed: two consecutive steps issued different launch sequences: " + diff)
+            if e._plan_tries >= 3:
+                e._plan_off = True
+                import warnings
+                warnings.warn("semseg_amd.Trainer: the step is not replayable (%s); it stays on the launch-by-launch path" % diff)
+            return out
+        e._plan, e._plan_out, e._plan_replays = plan, out, 0
+        e._plan_gen = _engine.ARENA_GEN[0]
+        msg = "recorded: %d launches in %d segments, %d host operations; verified against the previous step's record" % (
+            plan.launches(), len(plan.segments) - plan.host_ops(), plan.host_ops())
+        if self.use_graph and plan.host_ops() == 0:
+            try:
+                msg += "; hipGraph of %d nodes" % plan.capture_graph(st)
+            except PlanError as err:
+                msg += "; no graph (%s)" % err
+        self.plan_log.append(msg)
+        return out
 
     def check_labels(self):
         """Blocks until the out-of-range-label counts of every step so far are on the host; raises IndexError if a step
@@ -151,3 +294,4 @@ class Trainer:
         this call — call it at epoch end and before validation)."""
         for e in self.engines.values():
             e.check_labels()
+        self._watch_exchange(wait=True)

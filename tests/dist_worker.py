@@ -33,6 +33,8 @@ def run(world, rank, steps=2, bucket_mb=8):
     dev = torch.device("cuda", 0)
     m = make_model().to(dev).train()
     tr = Trainer(m, base_lr=0.01, momentum=0.9, weight_decay=1e-4, bucket_mb=bucket_mb, sync_bn=True)
+    lr = float(os.environ.get("LR", "0.01"))
+    run.w0 = tr.flat_w.cpu().numpy().copy()
     gb = int(os.environ.get("GLOBAL_BATCH", "4"))
     x, y = data(gb)
     per = gb // world
@@ -40,16 +42,20 @@ def run(world, rank, steps=2, bucket_mb=8):
     losses = []
     w_first = None
     for it in range(steps):
-        _, ml, al = tr.step(xs, ys, lr=0.01)
+        _, ml, al = tr.step(xs, ys, lr=lr)
         losses.append((float(ml.item()), float(al.item())))
         if it == 0:
             w_first = tr.flat_w.cpu().numpy()
     torch.cuda.synchronize()
     from semseg_amd import syncbn_xchg
-    if world > 1 and syncbn_xchg.enabled():
-        syncbn_xchg.get(dev).check()          # raises if an exchange gave up waiting for a peer
+    xc = syncbn_xchg.DECISION.get(dev.index, (None, ""))
+    if xc[0] is not None:
+        xc[0].check()                         # raises if an exchange gave up waiting for a peer
+    print("SyncBN exchange of rank %d: %s" % (rank, xc[1]), flush=True)
     sd = m.state_dict()
     ncoll = max(e.syncbn_collectives_per_step for e in tr.engines.values())
+    print("step plan of rank %d: %s" % (rank, tr.plan_log), flush=True)
+    run.plan_log = list(tr.plan_log)
     return np.array(losses), tr.flat_w.cpu().numpy(), sd["layer0.1.running_var"].cpu().numpy(), \
         sd["cls.1.running_mean"].cpu().numpy(), w_first, ncoll
 
@@ -62,7 +68,7 @@ if __name__ == "__main__":
         dist.init_process_group("gloo", rank=rank, world_size=world)
     losses, w, rv, rm, w1, ncoll = run(world, rank, steps=int(os.environ.get("STEPS", "2")))
     np.savez(os.path.join(out, "rank%d_of%d.npz" % (rank, world)), losses=losses, w=w, rv=rv, rm=rm, w1=w1,
-             ncoll=ncoll)
+             ncoll=ncoll, plan_log=np.array(" | ".join(run.plan_log)), w0=run.w0)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

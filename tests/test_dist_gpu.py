@@ -160,6 +160,40 @@ def test_bucket_collectives_wait_for_both_gradient_streams(lagging, report):
         assert d["stale_without_join"][-1] == 0
 
 
+def test_two_ranks_replayed_step_plan(report):
+    """The N > 1 step under the step plan (semseg_amd/plan.py): C segments between the collectives, the SyncBN exchanges and
+    the gradient-bucket all-reduces re-issued as host operations in the recorded order.  Six steps on two ranks (2 eager, 2
+    recorded, 2 replayed) against the same six steps sequenced launch by launch (SEMSEG_STEP_PLAN=0): the replicas of the
+    replayed run stay BIT-identical (a dropped or reordered collective would split them).  The criterion for "the replay is
+    the step" is structural, not numerical: the Trainer accepts a record only when the NEXT step, issued launch by launch,
+    records the same calls with the same arguments and the host operations at the same places (semseg_plan_compare; the log
+    must say "verified").  A numerical bound cannot be sharp here: this 57 x 57 toy net at batch 1 per rank amplifies the
+    run-to-run atomics noise so much that steps 1 and 2 — the SAME launch-by-launch code in both runs — already differ by
+    1e-6 and 1e-4 between them at lr 1e-4 (5e-7 and 2.4e-3 at lr 1e-2), so the losses only get a sanity bound."""
+    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+    res = {}
+    for mode in ("0", "1"):
+        tmp = tempfile.mkdtemp(prefix="semseg_plan_dist%s_" % mode)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", STEPS="6", LR="1e-4", SEMSEG_STEP_PLAN=mode, SEMSEG_SYNCBN_XCHG="0")
+        subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, tmp],
+                              env=env, timeout=900)
+        res[mode] = [np.load(os.path.join(tmp, "rank%d_of2.npz" % k)) for k in range(2)]
+    p0, p1 = res["1"]
+    log = str(p0["plan_log"])
+    assert "recorded:" in log and "host operations" in log, log
+    nhost = int(log.split("segments, ")[1].split(" host")[0])
+    assert nhost >= int(p0["ncoll"]) + 2, log           # every SyncBN exchange + the gradient buckets + the wait before SGD
+    assert np.array_equal(p0["w"], p1["w"]) and np.array_equal(p0["rv"], p1["rv"]) and np.array_equal(p0["rm"], p1["rm"])
+    e0 = res["0"][0]
+    e_first = np.abs(p0["losses"][:1] - e0["losses"][:1]).max()
+    e_loss = np.abs(p0["losses"] - e0["losses"]).max(axis=1) / np.abs(e0["losses"]).max()
+    report("2-rank step plan (%s) vs launch-by-launch, lr 1e-4: replicas bit-identical after 2 replayed steps; losses per step %s"
+           % (log, " ".join("%.1e" % v for v in e_loss)))
+    assert "verified" in log
+    assert e_first == 0.0 and e_loss.max() < 5e-2
+
+
 def test_syncbn_peer_memory_exchange(report):
     """The opt-in SyncBN exchange through IPC-mapped fine-grained memory (csrc/xchg.hip, SEMSEG_SYNCBN_XCHG=1)
     with 2 and 4 processes on the test box's ONE GPU: (1) the raw exchange == rank-ordered fp64 sum of the ranks' vectors, bit
