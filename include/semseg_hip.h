@@ -71,7 +71,7 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 /* y[M][Co] = [relu]( conv(x) (*scale) (+bias) (+add) ) — scale/bias/relu fold an eval-mode BatchNorm
  * (+ReLU, +residual) into the epilogue; stats (optional, [2*Co] fp64, caller-zeroed) receives the
  * per-channel sum and sum of squares of y for the following BatchNorm.  tile_n in {64, 128} = output columns of a 128-row tile, or 1064 / 1128 = 64-row tiles of 64 / 128 columns (launches whose
- * 128-row grid would not fill the chip), or 2128 = the 256 x 128 bf16x3 GEMM kernel with a statistics / fused-reduction epilogue (gemm_bf16split.hip) where the
+ * 128-row grid would not fill the chip), or 2128 / 3128 = the bf16x3 GEMM kernel of gemm_bf16split.hip with 256 x 128 / 128 x 128 tiles and a statistics / fused-reduction epilogue where the
  * call is a plain row GEMM — SEMSEG_ARITH_BF16X3, 1x1, stride 1, no padding, nothing folded into the epilogue, whole 128-column panels; data gradients also: at most
  * one fused BatchNorm layer and Co <= 1024 — and the 128 x 128 tile otherwise;
  * w_fwd must have Co_pad = roundup(Co, tile_n) rows.  Ci % 32 == 0.  scratch (optional) enables

@@ -50,13 +50,13 @@ if __name__ == "__main__":
         del tr, m, x, y
         torch.cuda.empty_cache()
     tiles = dict(sorted((k, v) for k, v in ops.TILE_CHOICE.items() if k.endswith("|sp") == SPLIT))
-    doc = {"generated_by": "scripts/make_tile_table.py (3 x 3 launches per tile shape; 128 x 128 unless another wins by >= 3 %, code 2128 by >= 2 %)",
+    doc = {"generated_by": "scripts/make_tile_table.py (3 x 3 launches per tile shape; 128 x 128 unless another wins by >= 3 %, codes 2128 / 3128 by >= 2 %)",
            "tile_codes": "128 = 128x128, 64 = 128x64, 1128 = 64x128, 1064 = 64x64 (rows x columns); 2128 = forward of a 1x1 "
-                         "stride-1 conv on the 256x128 bf16x3 GEMM kernel (gemm_bf16split.hip)",
+                         "stride-1 conv (or its data gradient) on the 256x128 bf16x3 GEMM kernel (gemm_bf16split.hip), 3128 = the same kernel with 128x128 tiles",
            "configs": ["%s%d_%d_c%d_bs%d" % c for c in CONFIGS],
            "tiles": tiles,
            "ms_per_tile_code": {k: {str(c): t for c, t in v.items()} for k, v in sorted(ops.TILE_TIMES.items())}}
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as f:
         json.dump(doc, f, indent=0, sort_keys=False)
-    print("wrote %s: %d shapes, by tile code %s" % (out, len(tiles), {c: sum(1 for v in tiles.values() if v == c) for c in ops.TILE_CODES + (ops.TILE_SPLIT_GEMM,)}))
+    print("wrote %s: %d shapes, by tile code %s" % (out, len(tiles), {c: sum(1 for v in tiles.values() if v == c) for c in ops.TILE_CODES + ops.SPLIT_GEMM_CODES}))

@@ -1011,7 +1011,8 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
 // splitting K, so no partial slabs and no separate epilogue pass
 // 2128: the 256 x 128 bf16x3 GEMM kernel of gemm_bf16split.hip for eligible 1x1 convs (forward: semseg_conv_fwd, data gradient:
 // dgrad_impl), else 128
-static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064 || t == 1128 || t == 2128; }
+// 3128: the same kernel with 128 x 128 tiles (four waves), for grids of a small per-GPU batch
+static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064 || t == 1128 || t == 2128 || t == 3128; }
 
 
 // arith (include/semseg_hip.h): SEMSEG_ARITH_BF16X3 selects the SP = 3 instances of the 1x1 / 3x3 buffer-load kernels
@@ -1165,12 +1166,12 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
   a.Kc = Ci; a.Nout = Co; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * Ho * Wo; a.tiles_n = 0; a.stats_nslot = stats_nslot > 0 ? stats_nslot : 1;
   a.batch = 1; a.x_bs = a.w_bs = a.y_bs = a.add_bs = 0; a.bnr_n = 0; a.bnr_mask = nullptr; a.bnr_bits = nullptr;
-  if (tile_n == 2128) {
-    // the 256 x 128 bf16x3 GEMM kernel (gemm_bf16split.hip) for what is a plain row GEMM with statistics: 1x1, stride 1, no
+  if (tile_n == 2128 || tile_n == 3128) {
+    // the 256 x 128 (3128: 128 x 128) bf16x3 GEMM kernel (gemm_bf16split.hip) for what is a plain row GEMM with statistics: 1x1, stride 1, no
     // padding, nothing folded into the epilogue, whole 128-column panels; anything else runs the 128 x 128 implicit-GEMM tile
     const bool plain = R == 1 && S == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W && !bias && !scale && !relu && !add;
     if (arith == SEMSEG_ARITH_BF16X3 && plain && Co % 128 == 0 && (ldy & 3) == 0 && ldy >= Co && (((size_t)y | (size_t)x) & 15) == 0)
-      return semseg_split_gemm_conv1x1_fwd(x, ldx, w_fwd, y, ldy, a.M, Ci, Co, stats, a.stats_nslot, stream);
+      return semseg_split_gemm_conv1x1_fwd(x, ldx, w_fwd, y, ldy, a.M, Ci, Co, stats, a.stats_nslot, tile_n == 3128 ? 128 : 256, stream);
     tile_n = 128;
   }
   return conv_launch(false, a, tile_n, arith, scratch, scratch_floats, stream);
@@ -1183,8 +1184,8 @@ static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx
   if (!dy || !w_dgrad || !dx || (lddy & 3) || !tile_code_ok(tile_n) || !arith_ok(arith)) return SEMSEG_EINVAL;
   const int Kc = (Co + 31) / 32 * 32;
   if (lddy < Kc) return SEMSEG_EINVAL;
-  if (tile_n == 2128) {
-    // the 256 x 128 bf16x3 GEMM kernel (gemm_bf16split.hip): 1x1, stride 1, no padding, whole 128-column panels, at most one
+  if (tile_n == 2128 || tile_n == 3128) {
+    // the 256 x 128 (3128: 128 x 128) bf16x3 GEMM kernel (gemm_bf16split.hip): 1x1, stride 1, no padding, whole 128-column panels, at most one
     // fused BatchNorm layer, and a reduction of at most 1024: that kernel accumulates ONE fp32 chain (no registers for the
     // second accumulator set this file flushes chains longer than 576 into).  Measured in situ (PSPNet-101 473^2, every
     // eligible layer forced onto it, K up to 2048): rms error 1.7 x the CPU-fp32 recompute's at worst (K = 2048), 2.6 x in the
@@ -1199,7 +1200,8 @@ static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx
                                              on ? bnr->bnr_bits : nullptr, on ? bnr->bnr_ldb : 0,
                                              on ? bnr->bnr_y[0] : nullptr, on ? bnr->bnr_ldy[0] : 0,
                                              on ? bnr->bnr_mean[0] : nullptr, on ? bnr->bnr_invstd[0] : nullptr,
-                                             on ? bnr->bnr_sums[0] : nullptr, on ? bnr->stats_nslot : 1, stream);
+                                             on ? bnr->bnr_sums[0] : nullptr, on ? bnr->stats_nslot : 1,
+                                             tile_n == 3128 ? 128 : 256, stream);
     }
     tile_n = 128;
   }

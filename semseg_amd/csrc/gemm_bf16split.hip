@@ -23,7 +23,7 @@
 namespace {
 
 
-constexpr int SB_BM = 256, SB_BN = 128, SB_THREADS = 512;
+constexpr int SB_BN = 128;     // output columns per workgroup; rows: template parameter BM_ (256: 8 waves, 128: 4 waves)
 #ifndef SB_NBUF
 #define SB_NBUF 2      // 1: the single-buffered K loop of rounds 3-4 (two barriers per K step; A/B builds only)
 #endif
@@ -112,8 +112,11 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[NS]) {
 // EPI 0: C is stored (the batched row GEMM of the Winograd path).  EPI 1: a 1x1 stride-1 convolution's forward — the same GEMM on
 // the NHWC activation and the packed forward panel — with the per-channel fp64 statistics of the following BatchNorm taken
 // from the accumulators, as conv_igemm_kernel's epilogue takes them.
-template <int NS, int BK, int EPI = 0>
-__global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(const SplitArgs p) {
+// BM_ = 128 (round 5): the same kernel with four waves (2 x 2) for grids whose 256-row tiles would leave most of the chip idle —
+// the 1x1 convs of a small per-GPU batch (57 tiles of 256 x 128 for a [7200 x 256] output on 256 CUs); three workgroups per CU.
+template <int NS, int BK, int EPI = 0, int BM_ = 256>
+__global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 4 : 3) void gemm_rows_bf16split_kernel(const SplitArgs p) {
+  constexpr int SB_BM = BM_, SB_THREADS = BM_ * 2, WM = BM_ / 64;      // WM row-waves x 2 column-waves of 64 x 64
   // LDS rows are BK bf16 wide, unpadded; the 16-byte chunks of a row are XOR-swizzled with the index of the 256-byte
   // group the row sits in, which makes both the 16-byte fragment reads (16 rows per LDS cycle, 64 banks) and the 8-byte
   // staging stores (128 contiguous bytes per 16 lanes, 32 banks) conflict-free.  (The first version padded rows by 16
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
   constexpr int SLAB_LD = 36;                                           // floats per slab row (conflict-free ds_read_b128)
   constexpr int STAGE_BYTES = NS * (SB_BM + SB_BN) * BK * 2;
   constexpr int SLAB_BYTES = (SB_THREADS / 64) * 32 * SLAB_LD * 4;
-  constexpr int RED2_BYTES = EPI == 2 ? 4 * SB_BN * 2 * 8 : 0;          // fp64 column sums of the fused reduction: [4 (wm)][SB_BN][2]
+  constexpr int RED2_BYTES = EPI == 2 ? WM * SB_BN * 2 * 8 : 0;         // fp64 column sums of the fused reduction: [WM (wm)][SB_BN][2]
   constexpr int EPI_BYTES = SLAB_BYTES + RED2_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[NBUF * STAGE_BYTES > EPI_BYTES ? NBUF * STAGE_BYTES : EPI_BYTES];
   auto sA = [&](int buf, int c) { return reinterpret_cast<__bf16*>(smem_raw + buf * STAGE_BYTES) + c * (SB_BM * BK); };
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
   float* C = p.c + (size_t)bi * p.c_bs;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % WM, wn = wave / WM;
   const int kq = tid % K4, r0 = tid / K4;
 
   const float* ga[A_PER];
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
       // lane = one column of block j, 32 of the wave's 64 rows in its registers: fp64 sums over them, the two lane halves
       // combined by a shuffle, the four row-waves through LDS (the staging area is idle: the K loop ended on a barrier),
       // then one atomic pair per column and workgroup into the slot replica of this row tile
-      double* red = reinterpret_cast<double*>(smem_raw);          // [4 (wm)][SB_BN][2]
+      double* red = reinterpret_cast<double*>(smem_raw);          // [WM (wm)][SB_BN][2]
       const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
         if (n0 + col < p.Nout) {
           double v = 0.0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v += red[(r * SB_BN + col) * 2 + which];
+          for (int r = 0; r < WM; ++r) v += red[(r * SB_BN + col) * 2 + which];
           atomic_add_f64(&p.stats[(size_t)(tm % p.nslot) * 2 * p.Nout + (size_t)which * p.Nout + n0 + col], v);
         }
       }
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(SB_THREADS, 4) void gemm_rows_bf16split_kernel(cons
       if (tid < SB_BN && n0 + tid < p.Nout) {
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < WM; ++r) {
           s1 += red2[(r * SB_BN + tid) * 2 + 0];
           s2 += red2[(r * SB_BN + tid) * 2 + 1];
         }
@@ -413,42 +416,49 @@ extern "C" int semseg_gemm_rows_batched_bf16split(const float* a, int lda, long 
   p.a = a; p.bt = bt; p.c = c;
   p.a_bs = a_bs; p.bt_bs = bt_bs; p.c_bs = c_bs;
   p.lda = lda; p.ldc = ldc; p.M = M; p.K = K; p.Nout = Nout;
-  p.tiles_m = (M + SB_BM - 1) / SB_BM;
   p.tiles_n = (Nout + SB_BN - 1) / SB_BN;
+  // 128-row tiles (four waves, three workgroups per CU) where 256-row tiles would occupy at most half of the 256 CUs
+  const bool small = nsplit == 3 && (long long)((M + 255) / 256) * p.tiles_n * batch <= 128;
+  const int bm = small ? 128 : 256;
+  p.tiles_m = (M + bm - 1) / bm;
   p.total = p.tiles_m * p.tiles_n * batch;
-  if (nsplit == 2 && bk == 32) gemm_rows_bf16split_kernel<2, 32><<<p.total, SB_THREADS, 0, stream>>>(p);
-  else if (nsplit == 2) gemm_rows_bf16split_kernel<2, 16><<<p.total, SB_THREADS, 0, stream>>>(p);
-  else gemm_rows_bf16split_kernel<3, 16><<<p.total, SB_THREADS, 0, stream>>>(p);
+  if (nsplit == 2 && bk == 32) gemm_rows_bf16split_kernel<2, 32><<<p.total, 512, 0, stream>>>(p);
+  else if (nsplit == 2) gemm_rows_bf16split_kernel<2, 16><<<p.total, 512, 0, stream>>>(p);
+  else if (small) gemm_rows_bf16split_kernel<3, 16, 0, 128><<<p.total, 256, 0, stream>>>(p);
+  else gemm_rows_bf16split_kernel<3, 16><<<p.total, 512, 0, stream>>>(p);
   return semseg_launch_status();
 }
 
-// tile code 2128 of semseg_conv_fwd (conv_igemm.hip): y[M][Co] = x[M][Ci] * w_fwd[Co_pad][Ci]^T + statistics, on the kernel above
+// tile codes 2128 (bm 256) / 3128 (bm 128) of semseg_conv_fwd (conv_igemm.hip): y[M][Co] = x[M][Ci] * w_fwd[Co_pad][Ci]^T + statistics, on the kernel above
 int semseg_split_gemm_conv1x1_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int M, int Ci, int Co,
-                                  double* stats, int nslot, hipStream_t stream) {
+                                  double* stats, int nslot, int bm, hipStream_t stream) {
   SplitArgs p;
   std::memset(&p, 0, sizeof(p));
   p.a = x; p.bt = w_fwd; p.c = y;
   p.a_bs = p.bt_bs = p.c_bs = 0;
   p.lda = ldx; p.ldc = ldy; p.M = M; p.K = Ci; p.Nout = Co;
-  p.tiles_m = (M + SB_BM - 1) / SB_BM;
+  if (bm != 128 && bm != 256) return SEMSEG_EINVAL;
+  p.tiles_m = (M + bm - 1) / bm;
   p.tiles_n = (Co + SB_BN - 1) / SB_BN;
   p.total = p.tiles_m * p.tiles_n;
   p.stats = stats; p.nslot = nslot > 0 ? nslot : 1;
-  gemm_rows_bf16split_kernel<3, 16, 1><<<p.total, SB_THREADS, 0, stream>>>(p);
+  if (bm == 128) gemm_rows_bf16split_kernel<3, 16, 1, 128><<<p.total, 256, 0, stream>>>(p);
+  else gemm_rows_bf16split_kernel<3, 16, 1><<<p.total, 512, 0, stream>>>(p);
   return semseg_launch_status();
 }
 
-// tile code 2128 of semseg_conv_dgrad / semseg_conv_dgrad_bnreduce: dx[M][Ci] = dy[M][Kc] * w_dgrad[Ci_pad][Kc]^T (+ add), with
+// tile codes 2128 (bm 256) / 3128 (bm 128) of semseg_conv_dgrad / semseg_conv_dgrad_bnreduce: dx[M][Ci] = dy[M][Kc] * w_dgrad[Ci_pad][Kc]^T (+ add), with
 // the fused BatchNorm-backward reduction of ONE layer when ybn is given
 int semseg_split_gemm_conv1x1_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int M, int Kc, int Ci,
                                     const float* add, int ldadd, const float* act, int ldact, const unsigned* relu_bits,
                                     int ldbits, const float* ybn, int ldybn, const float* mean, const float* invstd,
-                                    double* sums, int nslot, hipStream_t stream) {
+                                    double* sums, int nslot, int bm, hipStream_t stream) {
+  if (bm != 128 && bm != 256) return SEMSEG_EINVAL;
   SplitArgs p;
   std::memset(&p, 0, sizeof(p));
   p.a = dy; p.bt = w_dgrad; p.c = dx;
   p.lda = lddy; p.ldc = lddx; p.M = M; p.K = Kc; p.Nout = Ci;
-  p.tiles_m = (M + SB_BM - 1) / SB_BM;
+  p.tiles_m = (M + bm - 1) / bm;
   p.tiles_n = (Ci + SB_BN - 1) / SB_BN;
   p.total = p.tiles_m * p.tiles_n;
   p.nslot = nslot > 0 ? nslot : 1;
@@ -456,6 +466,7 @@ int semseg_split_gemm_conv1x1_dgrad(const float* dy, int lddy, const float* w_dg
   p.bnr_n = ybn ? 1 : 0;
   p.mask = relu_bits ? nullptr : act; p.ldm = ldact; p.bits = relu_bits; p.ldb = ldbits;
   p.ybn = ybn; p.ldybn = ldybn; p.mean = mean; p.invstd = invstd; p.sums = sums;
-  gemm_rows_bf16split_kernel<3, 16, 2><<<p.total, SB_THREADS, 0, stream>>>(p);
+  if (bm == 128) gemm_rows_bf16split_kernel<3, 16, 2, 128><<<p.total, 256, 0, stream>>>(p);
+  else gemm_rows_bf16split_kernel<3, 16, 2><<<p.total, 512, 0, stream>>>(p);
   return semseg_launch_status();
 }

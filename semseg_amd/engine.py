@@ -541,7 +541,8 @@ class Engine:
         ar = cl.arith if rs else ops.ARITH_F32       # the generic tap walk has no split instance
         tile = ops.chosen_tile("fwd", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, x.ld, out.ld, ar,
                                plain=fold is None and not (bias and m.bias is not None))
-        fam = ("gemm_rows_bf16split_kernel<3,16,1> (bf16x3, 1x1 conv + statistics)" if tile == ops.TILE_SPLIT_GEMM else
+        fam = ("gemm_rows_bf16split_kernel<3,16,1%s> (bf16x3, 1x1 conv + statistics)" % (",128" if tile == ops.TILE_SPLIT_GEMM_128 else "")
+               if tile in ops.SPLIT_GEMM_CODES else
                "conv_igemm_kernel<%d,%d,false,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)))
         ev = self._t0(fam, 2.0 * x.N * Ho * Wo * cl.Co * cl.Ci * cl.R * cl.S)
         if fold is not None:
@@ -623,8 +624,8 @@ class Engine:
             ar = cl.arith if rs else ops.ARITH_F32
             tile = ops.chosen_tile("dgrad", cl.pk, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil, y.ld, x.ld, ar,
                                    plain=not (fuse and len(bs["bns"]) > 1))
-            fam = ("gemm_rows_bf16split_kernel<3,16,2> (bf16x3, 1x1 data gradient + fused reduction)"
-                   if tile == ops.TILE_SPLIT_GEMM else
+            fam = ("gemm_rows_bf16split_kernel<3,16,2%s> (bf16x3, 1x1 data gradient + fused reduction)"
+                   % (",128" if tile == ops.TILE_SPLIT_GEMM_128 else "") if tile in ops.SPLIT_GEMM_CODES else
                    "conv_igemm_kernel<%d,%d,true,%d%s>(+splitk_epilogue)" % (64 if tile >= 1000 else 128, tile % 1000, rs, _fam(ar)))
             ev = self._t0(fam, flops)
             if fuse:

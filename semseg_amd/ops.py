@@ -115,9 +115,9 @@ def _load_tables():
         for k, v in load_tile_table(path).items():
             f = k.split("|")
             ncols = int(f[5]) if f[0] == "fwd" else int(f[4])      # fwd: Co columns, dgrad: Ci columns
-            if v not in TILE_CODES + (TILE_SPLIT_GEMM,) or (ncols < 128 and v % 1000 > 64):
+            if v not in TILE_CODES + SPLIT_GEMM_CODES or (ncols < 128 and v % 1000 > 64):
                 continue
-            if v == TILE_SPLIT_GEMM and not (k.endswith("|sp") and _split_gemm_eligible(k)):
+            if v in SPLIT_GEMM_CODES and not (k.endswith("|sp") and _split_gemm_eligible(k)):
                 continue
             out[k] = v
         try:
@@ -126,7 +126,7 @@ def _load_tables():
         except OSError:
             times = {}
         for k, v in out.items():
-            if v == TILE_SPLIT_GEMM and k in times:
+            if v in SPLIT_GEMM_CODES and k in times:
                 ig = {int(c): ms for c, ms in times[k].items() if int(c) in TILE_CODES}
                 if ig:
                     TILE_RUNNER_UP[k] = min(ig, key=ig.get)
@@ -135,7 +135,7 @@ def _load_tables():
 
 def plain_tile(tile, key, dflt, plain):
     """Tile code 2128 is for plain row GEMMs; anything else of that shape runs its best measured implicit-GEMM tile."""
-    if tile != TILE_SPLIT_GEMM or plain:
+    if tile not in SPLIT_GEMM_CODES or plain:
         return tile
     return TILE_RUNNER_UP.get(key, dflt)
 
@@ -156,6 +156,9 @@ TILE_CODES = (128, 64, 1128, 1064)   # 128x128, 128x64, 64x128, 64x64 (rows x co
 # 2128: semseg_conv_fwd runs the 256 x 128 bf16x3 GEMM kernel (gemm_bf16split.hip, the Winograd path's GEMM) with the statistics
 # epilogue instead of the implicit-GEMM kernel — bf16x3 table only, eligible shapes only (the library falls back to 128)
 TILE_SPLIT_GEMM = 2128
+TILE_SPLIT_GEMM_128 = 3128     # the same kernel with 128 x 128 tiles (four waves): grids of a small per-GPU batch (round 5)
+SPLIT_GEMM_CODES = (TILE_SPLIT_GEMM, TILE_SPLIT_GEMM_128)
+_FORCE_SPLIT_CODE = TILE_SPLIT_GEMM_128 if _os.environ.get("SEMSEG_FORCE_SPLIT_GEMM_BM") == "128" else TILE_SPLIT_GEMM   # with _FORCE_SPLIT_GEMM
 TILE_TIMES = {}   # key -> {tile code: ms per launch}, filled in tuning mode only
 # tile shapes measured with the SEMSEG_ARITH_BF16X3 instances of the kernels: keys suffixed "|sp"
 TILE_TABLE_SP_PATH = _os.environ.get("SEMSEG_TILE_TABLE_SP") or TILE_TABLE_PATH.replace("tile_table.json", "tile_table_sp.json")
@@ -169,9 +172,9 @@ def _tuned_tile(key, dflt, device, out_floats, launch, arith=ARITH_F32):
     if arith == ARITH_BF16X3:
         key = key + "|sp"
         if dflt == 128 and _split_gemm_eligible(key):
-            codes = codes + (TILE_SPLIT_GEMM,)
+            codes = codes + SPLIT_GEMM_CODES
             if _FORCE_SPLIT_GEMM:
-                return TILE_SPLIT_GEMM
+                return _FORCE_SPLIT_CODE
     t = TILE_CHOICE.get(key)
     if t is not None:
         return t if (dflt == 128 or t % 1000 == 64) else dflt
@@ -194,7 +197,7 @@ def _tuned_tile(key, dflt, device, out_floats, launch, arith=ARITH_F32):
     # 256 x 128 GEMM kernel (code 2128) by >= 2 %: it never needs the K-split epilogue launch, and taking it at 2-3 % measured
     # alone is worth 0.4 ms of the batch-16 step (interleaved A/B of the two tables, three rounds)
     t = min(codes, key=lambda c: best[c])
-    if best[t] >= (0.98 if t == TILE_SPLIT_GEMM else 0.97) * best[dflt]:
+    if best[t] >= (0.98 if t in SPLIT_GEMM_CODES else 0.97) * best[dflt]:
         t = dflt
     TILE_CHOICE[key] = t
     TILE_TIMES[key] = {c: round(best[c] / 3, 4) for c in codes}
@@ -235,7 +238,7 @@ def chosen_tile(kind, pk, N, H, W, stride, pad, dil, ld_in, ld_out, arith=ARITH_
     dflt = pk.tile_fwd if kind == "fwd" else pk.tile_dgrad
     key = tile_key(kind, N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil) + ("|sp" if arith == ARITH_BF16X3 else "")
     if _FORCE_SPLIT_GEMM and dflt == 128 and arith == ARITH_BF16X3 and _split_gemm_eligible(key):
-        return plain_tile(TILE_SPLIT_GEMM, key, dflt, plain)
+        return plain_tile(_FORCE_SPLIT_CODE, key, dflt, plain)
     t = TILE_CHOICE.get(key, dflt)
     return plain_tile(t if (dflt == 128 or t % 1000 == 64) else dflt, key, dflt, plain)
 

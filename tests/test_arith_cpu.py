@@ -102,7 +102,7 @@ def test_committed_tile_tables_are_well_formed():
         tiles = json.load(open(path))["tiles"]
         assert tiles and all(k.endswith("|sp") == sp for k in tiles)
         # code 2128 (the 256 x 128 bf16x3 GEMM kernel for 1x1 forward convs) only in the bf16x3 table, only for eligible shapes
-        assert all(int(v) in ops.TILE_CODES or (sp and int(v) == ops.TILE_SPLIT_GEMM and ops._split_gemm_eligible(k))
+        assert all(int(v) in ops.TILE_CODES or (sp and int(v) in ops.SPLIT_GEMM_CODES and ops._split_gemm_eligible(k))
                    for k, v in tiles.items())
         assert all(k.split("|")[0] in ("fwd", "dgrad") for k in tiles)
         for k, v in tiles.items():          # column width never exceeds the padding of the layer's packed panels

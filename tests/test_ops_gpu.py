@@ -108,8 +108,9 @@ def test_conv_dgrad_fused_bn_backward_reduce(case, mask, report):
     (1, 17, 19, 64, 128),       # one column tile, M = 323
     (2, 20, 20, 512, 384),      # three column tiles
 ])
-def test_conv_fwd_1x1_on_the_split_gemm_kernel(case, report, monkeypatch):
-    """Tile code 2128 of semseg_conv_fwd: the forward of a 1x1 stride-1 conv under SEMSEG_ARITH_BF16X3 on the 256 x 128 GEMM
+@pytest.mark.parametrize("code", [2128, 3128])
+def test_conv_fwd_1x1_on_the_split_gemm_kernel(case, code, report, monkeypatch):
+    """Tile codes 2128 (256 x 128 tiles) / 3128 (128 x 128 tiles, round 5) of semseg_conv_fwd: the forward of a 1x1 stride-1 conv under SEMSEG_ARITH_BF16X3 on the 256 x 128 GEMM
     kernel of gemm_bf16split.hip with the fp64 statistics epilogue; operands in wider buffers, replicated statistics slots.
     Same bounds as the implicit-GEMM kernel; an ineligible call (bias in the epilogue) silently takes the 128 x 128 tile."""
     from semseg_amd import ops
@@ -125,7 +126,8 @@ def test_conv_fwd_1x1_on_the_split_gemm_kernel(case, report, monkeypatch):
     xb[..., 32:32 + Ci] = nhwc(x).to(DEV)
     NS = ops.NSLOT
     monkeypatch.setattr(ops, "_FORCE_SPLIT_GEMM", True)
-    assert ops.chosen_tile("fwd", pk, N, H, W, 1, 0, 1, ldx, ldy, ops.ARITH_BF16X3) == ops.TILE_SPLIT_GEMM
+    monkeypatch.setattr(ops, "_FORCE_SPLIT_CODE", code)
+    assert ops.chosen_tile("fwd", pk, N, H, W, 1, 0, 1, ldx, ldy, ops.ARITH_BF16X3) == code
     yb = torch.full((N, H, W, ldy), float("nan"), device=DEV)
     st = torch.zeros(NS * 2 * Co, dtype=torch.float64, device=DEV)
     ops.conv_fwd(xb[..., 32:], ldx, pk, yb, ldy, N, H, W, 1, 0, 1, stats=st, nslot=NS, arith=ops.ARITH_BF16X3)
@@ -138,7 +140,7 @@ def test_conv_fwd_1x1_on_the_split_gemm_kernel(case, report, monkeypatch):
     yb2 = torch.empty(N, H, W, Co, device=DEV)
     ops.conv_fwd(xb[..., 32:], ldx, pk, yb2, Co, N, H, W, 1, 0, 1, bias=bias.to(DEV), arith=ops.ARITH_BF16X3)
     e_b = relerr(nchw(yb2), y64 + bias.double().view(1, -1, 1, 1))
-    report("1x1 forward on the 256x128 bf16x3 GEMM kernel %s: y %.2e stats %.2e (fallback with bias %.2e)" % (case, e_f, e_s, e_b))
+    report("1x1 forward on the bf16x3 GEMM kernel, tile code %d %s: y %.2e stats %.2e (fallback with bias %.2e)" % (code, case, e_f, e_s, e_b))
     assert max(e_f, e_b) < 2e-5 and e_s < 1e-5
 
 
@@ -150,8 +152,9 @@ def test_conv_fwd_1x1_on_the_split_gemm_kernel(case, report, monkeypatch):
     (1, 17, 19, 128, 512, True),       # K = 512, one column tile, M = 323 (a partial 256-row tile)
     (2, 16, 16, 256, 1024, False),     # layer3 conv3's data gradient: K = 1024, the longest chain the kernel is given
 ])
-def test_conv_dgrad_1x1_on_the_split_gemm_kernel(case, mask, report, monkeypatch):
-    """Tile code 2128 of semseg_conv_dgrad / semseg_conv_dgrad_bnreduce: the data gradient of a 1x1 stride-1 conv under
+@pytest.mark.parametrize("code", [2128, 3128])
+def test_conv_dgrad_1x1_on_the_split_gemm_kernel(case, mask, code, report, monkeypatch):
+    """Tile codes 2128 / 3128 of semseg_conv_dgrad / semseg_conv_dgrad_bnreduce: the data gradient of a 1x1 stride-1 conv under
     SEMSEG_ARITH_BF16X3 on the 256 x 128 GEMM kernel, plain (+ add) and with the fused BatchNorm-backward reduction of one layer
     (mask none / activation / bits), against fp64; same bounds as the implicit-GEMM kernel."""
     from semseg_amd import ops
@@ -170,7 +173,8 @@ def test_conv_dgrad_1x1_on_the_split_gemm_kernel(case, mask, report, monkeypatch
     pk = ops.PackedConv(Co, Ci, 1, 1, DEV)
     pk.pack(w.to(DEV))
     monkeypatch.setattr(ops, "_FORCE_SPLIT_GEMM", True)
-    assert ops.chosen_tile("dgrad", pk, N, H, W, 1, 0, 1, 0, 0, ops.ARITH_BF16X3) == ops.TILE_SPLIT_GEMM
+    monkeypatch.setattr(ops, "_FORCE_SPLIT_CODE", code)
+    assert ops.chosen_tile("dgrad", pk, N, H, W, 1, 0, 1, 0, 0, ops.ARITH_BF16X3) == code
     ldy = ops.roundup(Co, 128)
     dyb = torch.zeros(N, H, W, ldy, device=DEV)
     dyb[..., :Co] = nhwc(dy).to(DEV)
@@ -191,8 +195,8 @@ def test_conv_dgrad_1x1_on_the_split_gemm_kernel(case, mask, report, monkeypatch
     tot = sums.view(NS, 2 * Ci).sum(0).cpu()
     xh = (ybn.double() - mean.double().view(1, -1, 1, 1)) * inv.double().view(1, -1, 1, 1)
     e_s = max(relerr(tot[:Ci], g64.sum((0, 2, 3))), relerr(tot[Ci:], (g64 * xh).sum((0, 2, 3))))
-    report("1x1 data gradient on the 256x128 bf16x3 GEMM kernel %s mask=%s: plain %.2e fused g %.2e sums %.2e"
-           % (case, mask, e_p, e_g, e_s))
+    report("1x1 data gradient on the bf16x3 GEMM kernel, tile code %d %s mask=%s: plain %.2e fused g %.2e sums %.2e"
+           % (code, case, mask, e_p, e_g, e_s))
     assert max(e_p, e_g, e_s) < 2e-5
 
 
@@ -1004,15 +1008,16 @@ def test_gemm_kmajor_batched_chunks_when_scratch_is_small(report):
                                 Co, B)
 
 
-@pytest.mark.parametrize("nsplit,bk", [(2, 16), (2, 32), (3, 16)])
-def test_gemm_rows_bf16split(nsplit, bk, report):
+@pytest.mark.parametrize("nsplit,bk,B", [(2, 16, 3), (2, 32, 3), (3, 16, 3), (3, 16, 40)])
+def test_gemm_rows_bf16split(nsplit, bk, B, report):
     """The split-bf16 row GEMM of the Winograd path (csrc/gemm_bf16split.hip; nsplit 3 = SEMSEG_ARITH_BF16X3, DESIGN.md
     section 8.4) against fp64 and next to the fp32 matrix-core kernel on the same operands — ragged last row tile, a
     column tile that is half padding, strided A and C, batch strides.  Bounds from the error model: three pieces / six
     products carry 24 mantissa bits (rms within 2x of the fp32 kernel's own rounding noise + 1e-7); two pieces / three
-    products (a measurement only, nothing in the engine selects it) carry 16 (rms <= 1e-5)."""
+    products (a measurement only, nothing in the engine selects it) carry 16 (rms <= 1e-5).  Batch 3 = 12 tiles of 256 rows: the
+    launcher takes the 128-row instance (four waves, round 5); batch 40 = 160 tiles: the 256-row instance."""
     from semseg_amd import ops
-    B, M, K, Nout, lda, ldc = 3, 300, 1024, 192, 1024 + 64, 192 + 64
+    M, K, Nout, lda, ldc = 300, 1024, 192, 1024 + 64, 192 + 64
     g = torch.Generator().manual_seed(17 + nsplit + bk)
     a = torch.randn(B, M, lda, generator=g)
     bt = torch.zeros(B, 256, K)                      # panel rows padded to 256, the padding stays zero
@@ -1027,7 +1032,7 @@ def test_gemm_rows_bf16split(nsplit, bk, report):
     assert torch.isnan(out[:, :, Nout:]).all()       # nothing written past Nout
     rms = lambda t: float((t[:, :, :Nout].cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     e, e32 = rms(out), rms(base)
-    report("gemm_rows_batched_bf16split nsplit %d bk %d: rms %.2e (fp32 matrix-core kernel %.2e)" % (nsplit, bk, e, e32))
+    report("gemm_rows_batched_bf16split nsplit %d bk %d batch %d: rms %.2e (fp32 matrix-core kernel %.2e)" % (nsplit, bk, B, e, e32))
     assert e <= (2.0 * e32 + 1e-7 if nsplit == 3 else 1e-5)
     with pytest.raises(ops.HipError):
         ops.gemm_rows_batched_bf16split(ad, lda, M * lda, btd, 256 * K, out, ldc, M * ldc, M, K, Nout, B, nsplit=3, bk=32)
