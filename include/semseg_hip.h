@@ -418,6 +418,11 @@ int semseg_plan_graph_nodes(void* plan, int graph);
 int semseg_stream_wait_stream(hipStream_t waiter, hipStream_t signaller);
 int semseg_step_state_set(float* lr_dev2, float lr, float lr_head, unsigned long long* drop_dev,
                           unsigned long long drop_offset, hipStream_t stream);
+/* semseg_step_state_set + the copies of the caller's batch (x) and targets (y) into the buffers the record points at, in ONE
+ * launch (any byte counts; 16-byte aligned addresses). */
+int semseg_step_begin(void* x_dst, const void* x_src, size_t x_bytes, void* y_dst, const void* y_src, size_t y_bytes,
+                      float* lr_dev2, float lr, float lr_head, unsigned long long* drop_dev, unsigned long long drop_offset,
+                      hipStream_t stream);
 int semseg_host_probe(unsigned long long* host_out, int a, long long b, size_t c, float d, double e, hipStream_t stream);
 
 #ifdef __cplusplus

@@ -939,11 +939,27 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   // rounds, take the one with the best fill (ties: fewer splits = fewer slabs to write and reduce).
   const int ROUND = 256 * occ_of[dma];
   const int wg1 = tiles * batch;     // workgroups per K slice
-  int ksplit = 1;
+  // Accuracy bound on the split (round 5): one fp32 accumulation chain covers at most WGRAD_MAX_CHAIN pixels.  The fill rule
+  // alone gives the large weight matrices of a batch-16 step few, long slices (layer4's 1x1 convs: 32-64 tiles -> 4-8 slices of
+  // 7 200-14 400 pixels), and the in-situ check at the headline batch measured their weight gradients at 4.3-5.1 x the
+  // CPU-fp32 recompute's rms error (criterion 3 x; 1.2-1.9 x at per-GPU batch 2, where the same rule gives 1 800-pixel
+  // chains; profiles/r05_insitu_b16.txt).  The error of a chain grows with its length; 2 048 pixels puts every layer of the step
+  // inside the criterion (layer4: 1.4-1.8 x afterwards) for 16-32 partial slabs instead of 4-8 on those ~10 launches: 114.7 vs
+  // 114.9 ms and 114.2 vs 115.1 ms per batch-16 step in two interleaved A/Bs (bound off / on).  Bounding the chains INSIDE the
+  // 128 x 256 kernel instead was measured in two forms and rejected: a second accumulator set in registers (the compiler moves
+  // ~300 instructions' worth of accumulators per stage: 116.1 -> 121.8-122.4 ms per step) and a flush of the accumulators into
+  // the workgroup's own partial slab every 2 048 pixels (the code between two chunks changes the schedule of the stage loop:
+  // 114.7 -> 119.5 ms).  Batched launches (the Winograd-domain weight gradients: 1.3 x in situ at batch 16) keep the fill rule.
+#ifndef WGRAD_MAX_CHAIN
+#define WGRAD_MAX_CHAIN 2048
+#endif
+  const int ks_min = batch == 1 ? (M + WGRAD_MAX_CHAIN - 1) / WGRAD_MAX_CHAIN : 1;
+  int ksplit = ks_min;
   {
     double best = 0.0;
-    const int ks_max = wg1 > ROUND / 2 ? 8 : (2 * ROUND + wg1 - 1) / wg1;
-    for (int ks = 1; ks <= ks_max; ++ks) {
+    const int ks_fill = wg1 > ROUND / 2 ? 8 : (2 * ROUND + wg1 - 1) / wg1;
+    const int ks_max = ks_min > 1 ? ks_min + (ROUND + wg1 - 1) / wg1 : ks_fill;   // above the bound: the next full round
+    for (int ks = ks_min; ks <= (ks_max > ks_fill ? ks_max : ks_fill); ++ks) {
       const int wgs = wg1 * ks;
       const double eff = (double)wgs / (double)(((wgs + ROUND - 1) / ROUND) * ROUND);
       if (eff > best + 0.02) { best = eff; ksplit = ks; }

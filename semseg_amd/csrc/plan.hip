@@ -122,6 +122,26 @@ __global__ void step_state_kernel(float* lr2, float lr, float lr_head, unsigned 
   if (drop) drop[0] = off;
 }
 
+// One launch in front of a replayed step: the caller's input batch and targets into the buffers the record points at (any
+// byte count; 16-byte body + byte tail) and the per-step values into device memory.
+__global__ __launch_bounds__(256) void step_begin_kernel(unsigned char* xd, const unsigned char* xs, size_t xb, unsigned char* yd,
+                                                         const unsigned char* ys, size_t yb, float* lr2, float lr, float lr_head,
+                                                         unsigned long long* drop, unsigned long long off) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+  if (tid == 0) {
+    if (lr2) {
+      lr2[0] = lr;
+      lr2[1] = lr_head;
+    }
+    if (drop) drop[0] = off;
+  }
+  const size_t x16 = xb >> 4, y16 = yb >> 4;
+  for (size_t i = tid; i < x16; i += nth) reinterpret_cast<uint4*>(xd)[i] = reinterpret_cast<const uint4*>(xs)[i];
+  for (size_t i = tid; i < y16; i += nth) reinterpret_cast<uint4*>(yd)[i] = reinterpret_cast<const uint4*>(ys)[i];
+  for (size_t i = (x16 << 4) + tid; i < xb; i += nth) xd[i] = xs[i];
+  for (size_t i = (y16 << 4) + tid; i < yb; i += nth) yd[i] = ys[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -300,6 +320,20 @@ int semseg_step_state_set(float* lr_dev2, float lr, float lr_head, unsigned long
                           unsigned long long drop_offset, hipStream_t stream) {
   if (!lr_dev2 && !drop_dev) return SEMSEG_EINVAL;
   step_state_kernel<<<1, 1, 0, stream>>>(lr_dev2, lr, lr_head, drop_dev, drop_offset);
+  return semseg_launch_status();
+}
+
+int semseg_step_begin(void* x_dst, const void* x_src, size_t x_bytes, void* y_dst, const void* y_src, size_t y_bytes,
+                      float* lr_dev2, float lr, float lr_head, unsigned long long* drop_dev, unsigned long long drop_offset,
+                      hipStream_t stream) {
+  if ((x_bytes && (!x_dst || !x_src)) || (y_bytes && (!y_dst || !y_src))) return SEMSEG_EINVAL;
+  if ((((uintptr_t)x_dst | (uintptr_t)x_src | (uintptr_t)y_dst | (uintptr_t)y_src) & 15) != 0) return SEMSEG_EINVAL;
+  const size_t chunks = ((x_bytes > y_bytes ? x_bytes : y_bytes) >> 4) + 1;
+  size_t grid = (chunks + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  step_begin_kernel<<<(int)grid, 256, 0, stream>>>(static_cast<unsigned char*>(x_dst), static_cast<const unsigned char*>(x_src), x_bytes,
+                                                   static_cast<unsigned char*>(y_dst), static_cast<const unsigned char*>(y_src), y_bytes,
+                                                   lr_dev2, lr, lr_head, drop_dev, drop_offset);
   return semseg_launch_status();
 }
 

@@ -135,6 +135,7 @@ WINO_BF16X3_KERNEL = os.environ.get("SEMSEG_WINO_GEMM", "standalone")
 # SEMSEG_RELU_BITS=0: the fused BatchNorm-backward reductions read the post-ReLU activation as their mask (rounds 2-3) instead
 # of the bit mask bn_apply writes next to it
 RELU_BITS = os.environ.get("SEMSEG_RELU_BITS", "1") != "0"
+WGRAD_BF16X3_MAX_M = int(os.environ.get("SEMSEG_WGRAD_BF16X3_MAX_M", "131072"))   # longer weight-gradient reductions: exact fp32 products
 
 
 def set_arith(name):
@@ -567,9 +568,16 @@ class Engine:
         big = cl.Ci % 128 == 0 and cl.Co >= 128
         # 128 x 128 tiles run the direct-to-LDS kernel (conv_wgrad.hip: WGRAD_DMA_POLICY; under bf16x3 its SP = 3 form,
         # WGRAD_SP_POLICY) and 64 x 64 tiles the register-staged fp32 kernel
-        ev = self._t0(self._wgrad_family(big, cl.arith, cl.Ci), flops)
+        # Reductions longer than WGRAD_BF16X3_MAX_M pixels keep exact fp32 products: the three dropped cross products of
+        # bf16x3 are an error of ~2^-24 PER PRODUCT, which a sum over M products with heavy cancellation carries as sqrt(M),
+        # where the CPU's blocked fp32 sum grows much slower — in situ at the headline batch the 1x1 weight gradients at
+        # 119 x 119 (M = 226 576: layer1.0.conv1, layer1.0.downsample.0, layer2.0.conv1) measured 3.6-4.2 x the CPU-fp32
+        # recompute's rms error under bf16x3 (criterion 3 x) and 0.8-0.9 x with exact products (profiles/r05_insitu_b16.txt);
+        # at M = 57 600 (every layer3 / layer4 / head conv of a batch-16 step) bf16x3 is inside the criterion.
+        ar = cl.arith if y.M <= WGRAD_BF16X3_MAX_M else ops.ARITH_F32
+        ev = self._t0(self._wgrad_family(big, ar, cl.Ci), flops)
         ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
-                       cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil, arith=cl.arith)
+                       cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil, arith=ar)
         self._t1(ev)
         ready = [m.weight]
         if m.bias is not None:
@@ -807,15 +815,23 @@ class Engine:
     def _syncing(self):
         return (self.sync_bn or self.force_sync_bn) and self.dist_on
 
-    def _all_reduce(self, t):
+    def _all_reduce(self, t, src=None, nslot=1):
         """One SyncBN exchange: the peer-memory exchange kernel (semseg_amd/syncbn_xchg.py: one launch, no c10d call) when
-        it passed its start-up self-test among the job's ranks or is forced, RCCL otherwise."""
+        it passed its start-up self-test among the job's ranks or is forced, RCCL otherwise.  src / nslot: the vector still
+        lies in `nslot` slot replicas (src = [nslot][len(t)], t = its first slot): the exchange kernel folds them itself, the
+        RCCL path needs them folded first (semseg_bn_combine) — one launch less per forward BatchNorm layer on the former."""
         from . import syncbn_xchg
         xc = syncbn_xchg.active(self.device)
+        if src is not None and xc is None:
+            ops.bn_combine(src, nslot, t.numel() // 2)
+            src = None
 
         def exchange():
             if xc is not None:
-                xc.all_reduce(t)
+                if src is not None:
+                    xc.all_reduce(src, nslot=nslot, n=t.numel(), out=t)
+                else:
+                    xc.all_reduce(t)
             else:
                 dist.all_reduce(t)
         self.host_op(exchange)
@@ -851,8 +867,7 @@ class Engine:
             bls = [self.bns[bm] for bm, _ in train]
             if len(bls) == 1:
                 views = [bls[0].stats[:2 * bls[0].C]]
-                ops.bn_combine(bls[0].stats, ops.NSLOT, bls[0].C)
-                self._all_reduce(views[0])
+                self._all_reduce(views[0], src=bls[0].stats, nslot=ops.NSLOT)
             else:
                 g = self._group(bls)
                 views = [g.view(bl) for bl in bls]

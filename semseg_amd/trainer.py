@@ -209,10 +209,14 @@ class Trainer:
             plan = e._plan = None             # a process-wide arena the plan points into was replaced: record again
             self.plan_log.append("discarded: arena generation moved")
         if plan is not None:
-            e._plan_x.copy_(x)
-            e._plan_y.copy_(y)
             k = e._plan_replays + 1
-            self._set_step_state(e, lr, k * e._plan_drops)
+            # one launch: the caller's batch into the recorded input buffers + this step's learning rates / dropout counter
+            xs, ys = x.contiguous(), y.contiguous()
+            assert xs.dtype == e._plan_x.dtype and ys.dtype == e._plan_y.dtype and xs.shape == e._plan_x.shape and ys.shape == e._plan_y.shape
+            ops._ck(lib.raw("semseg_step_begin")(e._plan_x.data_ptr(), xs.data_ptr(), xs.numel() * xs.element_size(),
+                                                 e._plan_y.data_ptr(), ys.data_ptr(), ys.numel() * ys.element_size(),
+                                                 self._step_state.data_ptr(), float(lr), float(lr) * 10.0,
+                                                 e.drop_dev.data_ptr(), int(k * e._plan_drops), ops._stream()), "step_begin")
             e._drop_calls += e._plan_drops
             if self.dist_on:
                 e._works = []

@@ -30,6 +30,10 @@ def _case(report, name, arch, layers, classes, size, batch, psa_cfg=None, oracle
     chk, ml, al = run_insitu(m, x.cuda(), y.cuda(), report, only=only)
     report("in-situ backward parity, %s: %d quantities over %d ops\n%s"
            % (name, len(chk.rows), len({(r[0], r[1]) for r in chk.rows}), chk.summary()))
+    if only is not None:      # the sampled batch-16 run keeps every weight-gradient row (the quantity whose error grows with the batch)
+        report("\n".join("    %-28s %-11s rms hip %.2e cpu-fp32 %.2e ratio %.2f   max-abs ratio %.2f"
+                         % (r[1], r[2], r[5], r[6], r[5] / max(r[6], 1e-30), r[3] / max(r[4], 1e-30))
+                         for r in chk.rows if r[2].startswith("wgrad")))
     if oracle_loss:
         with torch.no_grad():
             _, ml_ref, al_ref = segnet.forward({k: v.clone() for k, v in sd.items()}, x, layers, arch, training=True,
