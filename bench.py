@@ -28,7 +28,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 ISO_STEPS = 2
-PMC_FILE = "r04_pmc_per_kernel.json"   # per-kernel HBM bytes / MFMA-busy from the rocprofv3 --pmc passes of this round
+PMC_FILE = "r05_pmc_per_kernel.json"   # per-kernel HBM bytes / MFMA-busy from the rocprofv3 --pmc passes of this round
 
 
 def conv_flops_per_image(model, size):
@@ -328,7 +328,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)      # >= 4: two launch-by-launch steps + the two recorded steps of the step plan
     ap.add_argument("--layers", type=int, default=101)
     ap.add_argument("--size", type=int, default=473)
     ap.add_argument("--classes", type=int, default=150)

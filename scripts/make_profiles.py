@@ -17,8 +17,12 @@ def family(k):
     if m: return 'conv_wgrad_kernel<%s,%s%s>' % (m.group(1), m.group(2), ',SP3' if m.group(3) == '3' else '')
     m = re.match(r'conv_igemm_kernel<(\d+), (\d+), (true|false), (\d+), (?:true|false)(?:, (\d))?>', k)
     if m: return 'conv_igemm_kernel<%s,%s,%s,%s%s>' % (m.group(1), m.group(2), m.group(3), m.group(4), ',SP3' if m.group(5) == '3' else '')
-    m = re.match(r'gemm_rows_bf16split_kernel<(\d+), (\d+)(?:, (\d+))?>', k)      # third parameter: epilogue (0 plain, 1 statistics, 2 data gradient)
-    if m: return 'gemm_rows_bf16split_kernel<%s,%s%s>' % (m.group(1), m.group(2), '' if m.group(3) in (None, '0') else ',' + m.group(3))
+    m = re.match(r'gemm_rows_bf16split_kernel<(\d+), (\d+)(?:, (\d+))?(?:, (\d+))?>', k)      # third parameter: epilogue (0 plain, 1 statistics, 2 data gradient); fourth: rows per tile (256 | 128)
+    if m:
+        epi = '' if m.group(3) in (None, '0') else ',' + m.group(3)
+        bm = ',128' if m.group(4) == '128' else ''
+        if bm and not epi: epi = ',0'
+        return 'gemm_rows_bf16split_kernel<%s,%s%s%s>' % (m.group(1), m.group(2), epi, bm)
     return k
 def agg(path):
     a = collections.defaultdict(lambda: collections.defaultdict(float)); seen = collections.defaultdict(dict)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): the bench lines behind the small-batch / multi-GPU-readiness statements of DESIGN.md
 # (a claim without a kept bench line is not evidence).  Digest: copy gpurun_out/<tag>_*.json to profiles/.
-tag=${1:-r04}
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
 line() { grep "^{\"metric\"" "$1" | tail -1; }
@@ -19,6 +19,9 @@ timeout 300 python bench.py --size 713 --classes 19 --global-batch 2 --steps 16 
 timeout 400 python bench.py --arch psa --size 465 --steps 8 --warmup 2 --no-cpu-baseline --module-steps 0 > $out/${tag}_psanet.log 2>&1; line $out/${tag}_psanet.log > $out/${tag}_psanet.json
 # two-stream backward vs everything on one stream, final code
 timeout 300 python scripts/ab_libs.py $out/${tag}_two_stream_ab.json 16 2 two_stream one_stream::SEMSEG_SIDE_WGRAD=0+SEMSEG_HIPRI_MAIN=0 > $out/${tag}_two_stream_ab.log 2>&1
+# host issue time of the three step drivers (launch by launch / C replay / hipGraph) at per-GPU batch 2 and 16
+timeout 300 python scripts/host_issue_time.py 2 $out/${tag}_host_issue_b2.json > $out/${tag}_host_issue_b2.log 2>&1
+timeout 300 python scripts/host_issue_time.py 16 $out/${tag}_host_issue_b16.json > $out/${tag}_host_issue_b16.log 2>&1
 timeout 200 python scripts/psamask_bench.py > $out/${tag}_psamask_bench.log 2>&1
 timeout 200 python scripts/bench_infer.py > $out/${tag}_infer.log 2>&1
 for f in bs2 bs2_forced_rccl bs2_forced_xchg bs4 bs8 config3_713 psanet; do echo $f; cut -c1-260 $out/${tag}_$f.json; done

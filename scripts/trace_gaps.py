@@ -22,6 +22,7 @@ for s, e, _, _ in sel[1:]:
 union += cur_e - cur_s
 fam = collections.Counter()
 for s, e, n, _ in sel:
+    n = n.replace("void ", "").replace("(anonymous namespace)::", "")
     fam[n.split("(")[0][:60]] += e - s
 print("kernels %d over %d steps: span %.3f ms/step, sum of durations %.3f ms/step, union (GPU not idle) %.3f ms/step, idle %.3f ms/step"
       % (len(sel), steps, span / steps, busy / steps, union / 1e6 / steps, (span - union / 1e6) / steps))
