@@ -227,7 +227,8 @@ int semseg_bn_param_grads(double* sums, int nslot, float* dgamma, float* dbeta, 
  * (hipIpcMemHandle_t, 64 bytes) and maps every peer's (semseg_xchg_ipc_import); peer_bases = HOST array of the `world`
  * mapped base pointers in rank order (own buffer at [rank]).  allreduce: out[0:n] = sum over ranks of (sum over the nslot
  * replicas of in[nslot][n]), summed in rank order on every rank (bit-identical results); seq = 1, 2, ... must advance by
- * one per call, identically on every rank; n <= SEMSEG_XCHG_MAX_DOUBLES.  A rank whose peers do not arrive within timeout_ms
+ * one per call, identically on every rank — by value, or (seq_dev non-null; seq ignored) kept in device memory and advanced
+ * by the kernel itself, which leaves the launch without a per-call host argument: a recorded step replays it; n <= SEMSEG_XCHG_MAX_DOUBLES.  A rank whose peers do not arrive within timeout_ms
  * (<= 0: 20 000) sets *err_dev = 1 and returns garbage in out (the caller checks err_dev); once *err_dev is set every later
  * exchange gives up at once.  Verified with several processes on one GPU only: the host side takes this path after a start-up
  * self-test among the real peers and uses RCCL otherwise (semseg_amd/syncbn_xchg.py). */
@@ -239,7 +240,8 @@ int semseg_xchg_ipc_export(void* ptr, void* handle64);
 int semseg_xchg_ipc_import(const void* handle64, void** ptr);
 int semseg_xchg_ipc_close(void* ptr);
 int semseg_xchg_allreduce_f64(const double* in, int nslot, int n, double* out, void* const* peer_bases, int world, int rank,
-                              unsigned long long seq, int* err_dev, int timeout_ms, hipStream_t stream);
+                              unsigned long long seq, unsigned long long* seq_dev, int* err_dev, int timeout_ms,
+                              hipStream_t stream);
 
 /* ---- spatial ops: MaxPool2d(3,2,1) model/resnet.py:115; AdaptiveAvgPool2d model/pspnet.py:14;
  * F.interpolate(bilinear, align_corners=True) model/pspnet.py:25,95,100; model/psanet.py:61,78,97. */

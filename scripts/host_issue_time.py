@@ -12,7 +12,14 @@ from semseg_amd.trainer import Trainer
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 res = {"batch": B}
-for mode in ("eager", "plan", "graph"):
+# the N > 1 code path on one rank: SEMSEG_FORCE_DIST=1 python -m torch.distributed.run --nproc-per-node 1 ... host_issue_time.py
+DIST = os.environ.get("SEMSEG_FORCE_DIST") == "1" and "RANK" in os.environ
+if DIST:
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    res["path"] = "N > 1 code path on one rank, SyncBN exchange " + os.environ.get("SEMSEG_SYNCBN_XCHG", "auto")
+for mode in (("eager", "plan") if DIST else ("eager", "plan", "graph")):
     torch.manual_seed(0)
     m = PSPNet(layers=101, classes=150, zoom_factor=8, pretrained=False).cuda().train()
     tr = Trainer(m, base_lr=0.01, sync_bn=True)

@@ -38,6 +38,7 @@ struct XchgArgs {
   double* out;                    // [n]
   int* err;
   unsigned long long seq;
+  unsigned long long* seq_dev;      // non-null: the exchange number lives in device memory (seq = *seq_dev + 1, written back at the end)
   unsigned long long limit_ticks;   // bound of the flag wait in ticks of the 100 MHz constant clock
   int world, rank, nslot, n;
 };
@@ -50,7 +51,12 @@ __device__ __forceinline__ unsigned long long* flags_of(double* base, int world,
 }
 
 __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(const XchgArgs p) {
-  const int tid = threadIdx.x, W = p.world, par = (int)(p.seq & 1ull);
+  // Exchange number from device memory (round 5): every rank's counter advances by one per exchange, in the same call
+  // sequence, so the launch has no per-call host argument and a recorded step plan can replay it (csrc/plan.hip).  Every
+  // thread reads the counter before the first barrier; thread 0 writes it back after the last one.  (The argument struct stays
+  // const: a modified copy of it moved the dynamically indexed peer[] array into scratch memory — 7 us per exchange.)
+  const unsigned long long seq = p.seq_dev ? p.seq_dev[0] + 1ull : p.seq;
+  const int tid = threadIdx.x, W = p.world, par = (int)(seq & 1ull);
   // (a) fold the slot replicas of the local vector, (b) store it into slot [rank] of every peer's buffer
   for (int i = tid; i < p.n; i += blockDim.x) {
     double v = p.in[i];
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(const XchgArgs p) 
   __syncthreads();
   // (c) raise this rank's flag in every peer's buffer
   if (tid < W)
-    __hip_atomic_store(flags_of(p.peer[(p.rank + tid) % W], W, par) + p.rank, p.seq, __ATOMIC_RELEASE,
+    __hip_atomic_store(flags_of(p.peer[(p.rank + tid) % W], W, par) + p.rank, seq, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
   // (d) wait for every rank's flag in the own buffer (bounded)
   __shared__ int bad;
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(const XchgArgs p) 
     // 1 s bound fired once in the two-processes-on-one-GPU test), so it is 20 s; an exchange that already failed in this
     // process makes the following ones give up at once instead of waiting 20 s each.
     const unsigned long long t0 = wall_clock64(), limit = *p.err ? 0ull : p.limit_ticks;
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.seq) {
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       __builtin_amdgcn_s_sleep(16);
       if (wall_clock64() - t0 > limit) {      // a peer never arrived (crashed, different call sequence, not co-resident)
         bad = 1;
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(const XchgArgs p) 
       v += __hip_atomic_load(slot_of(mine, W, par, q) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     p.out[i] = v;
   }
+  if (p.seq_dev && tid == 0) p.seq_dev[0] = seq;      // ordered after every thread's read by the barriers above
 }
 
 }  // namespace
@@ -153,15 +160,16 @@ int semseg_xchg_ipc_import(const void* handle64, void** ptr) {
 int semseg_xchg_ipc_close(void* ptr) { return (!ptr || hipIpcCloseMemHandle(ptr) == hipSuccess) ? SEMSEG_OK : SEMSEG_ELAUNCH; }
 
 int semseg_xchg_allreduce_f64(const double* in, int nslot, int n, double* out, void* const* peer_bases, int world, int rank,
-                              unsigned long long seq, int* err_dev, int timeout_ms, hipStream_t stream) {
+                              unsigned long long seq, unsigned long long* seq_dev, int* err_dev, int timeout_ms,
+                              hipStream_t stream) {
   if (!in || !out || !peer_bases || !err_dev || world < 1 || world > XCHG_MAX_WORLD || rank < 0 || rank >= world ||
-      nslot < 1 || n < 1 || n > XCHG_MAX || seq == 0)
+      nslot < 1 || n < 1 || n > XCHG_MAX || (seq == 0 && !seq_dev))
     return SEMSEG_EINVAL;
   XchgArgs a;
   for (int q = 0; q < XCHG_MAX_WORLD; ++q) a.peer[q] = q < world ? static_cast<double*>(peer_bases[q]) : nullptr;
   for (int q = 0; q < world; ++q)
     if (!a.peer[q]) return SEMSEG_EINVAL;
-  a.in = in; a.out = out; a.err = err_dev; a.seq = seq;
+  a.in = in; a.out = out; a.err = err_dev; a.seq = seq; a.seq_dev = seq_dev;
   a.limit_ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 20000) * 100000ull; a.world = world; a.rank = rank; a.nslot = nslot; a.n = n;
   xchg_allreduce_kernel<<<1, 1024, 0, stream>>>(a);
   return semseg_launch_status();

@@ -135,6 +135,7 @@ WINO_BF16X3_KERNEL = os.environ.get("SEMSEG_WINO_GEMM", "standalone")
 # SEMSEG_RELU_BITS=0: the fused BatchNorm-backward reductions read the post-ReLU activation as their mask (rounds 2-3) instead
 # of the bit mask bn_apply writes next to it
 RELU_BITS = os.environ.get("SEMSEG_RELU_BITS", "1") != "0"
+XCHG_HOST_OP = os.environ.get("SEMSEG_XCHG_HOST_OP", "0") == "1"
 WGRAD_BF16X3_MAX_M = int(os.environ.get("SEMSEG_WGRAD_BF16X3_MAX_M", "131072"))   # longer weight-gradient reductions: exact fp32 products
 
 
@@ -826,15 +827,21 @@ class Engine:
             ops.bn_combine(src, nslot, t.numel() // 2)
             src = None
 
-        def exchange():
-            if xc is not None:
+        if xc is not None:
+            # one launch on the compute stream, exchange number in device memory: an entry of the recorded step like any other
+            # (SEMSEG_XCHG_HOST_OP=1: issued as a host operation between two C segments instead, the form before the counter
+            # moved into device memory; A/B only)
+            def exchange():
                 if src is not None:
                     xc.all_reduce(src, nslot=nslot, n=t.numel(), out=t)
                 else:
                     xc.all_reduce(t)
+            if XCHG_HOST_OP:
+                self.host_op(exchange)
             else:
-                dist.all_reduce(t)
-        self.host_op(exchange)
+                exchange()
+        else:
+            self.host_op(lambda: dist.all_reduce(t))
         self.syncbn_collectives_per_step += 1
 
     def host_op(self, fn):

@@ -42,7 +42,7 @@ def _slot(ct, a, name, i):
 
 # entry points that synchronise with the host or whose arguments are host memory: a step that calls one while recording
 # cannot be replayed
-_NOT_REPLAYABLE = ("semseg_label_check", "semseg_xchg_", "semseg_aug", "semseg_plan_")
+_NOT_REPLAYABLE = ("semseg_label_check", "semseg_xchg_alloc", "semseg_xchg_free", "semseg_xchg_ipc", "semseg_aug", "semseg_plan_")
 
 
 class StepPlan:

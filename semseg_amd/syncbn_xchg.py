@@ -141,6 +141,9 @@ class SyncExchange:
             if self.failed is None:
                 self._peers = (ctypes.c_void_p * self.world)(*ptrs)
             self.err = torch.zeros(1, dtype=torch.int32, device=device)
+            # the exchange number lives in device memory and is advanced by the kernel: no per-call host argument, so a recorded
+            # step plan replays the exchanges inside its C segments (no host operation per SyncBN layer)
+            self.seq_dev = torch.zeros(1, dtype=torch.int64, device=device)
             self._host = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
         self._events = [None] * self.RING
         self._nwatch = 0
@@ -163,9 +166,9 @@ class SyncExchange:
         n = t.numel() // nslot if n is None else n
         out = t if out is None else out
         assert n <= MAX_DOUBLES and out.numel() >= n
-        self.seq += 1
-        self._ck(lib.semseg_xchg_allreduce_f64(t.data_ptr(), nslot, n, out.data_ptr(), self._peers, self.world, self.rank,
-                                               self.seq, self.err.data_ptr(), self.timeout_ms,
+        self.seq += 1          # host mirror of the device counter (diagnostics, reset)
+        self._ck(lib.semseg_xchg_allreduce_f64(t.data_ptr(), nslot, n, out.data_ptr(), ctypes.addressof(self._peers), self.world,
+                                               self.rank, 0, self.seq_dev.data_ptr(), self.err.data_ptr(), self.timeout_ms,
                                                torch.cuda.current_stream().cuda_stream), "xchg_allreduce_f64")
 
     def selftest(self, rounds=64, timeout_ms=2000):
@@ -246,9 +249,11 @@ class SyncExchange:
         """Explicit re-handshake after a time-out: COLLECTIVE — every rank drains its stream, the ranks meet at a barrier,
         the flag is cleared and the sequence numbers restart from a common value."""
         torch.cuda.synchronize(self.device)
-        seq = torch.tensor([self.seq], dtype=torch.int64, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        seq = torch.tensor([int(self.seq_dev.item())], dtype=torch.int64,
+                           device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(seq, op=dist.ReduceOp.MAX, group=self.group)
         self.seq = int(seq.item()) + 2          # both parities' stale flags are below it on every rank
+        self.seq_dev.fill_(self.seq)
         self.err.zero_()
         self._events = [None] * self.RING
         torch.cuda.synchronize(self.device)

@@ -160,7 +160,8 @@ def test_bucket_collectives_wait_for_both_gradient_streams(lagging, report):
         assert d["stale_without_join"][-1] == 0
 
 
-def test_two_ranks_replayed_step_plan(report):
+@pytest.mark.parametrize("xchg", ["0", "1"])
+def test_two_ranks_replayed_step_plan(xchg, report):
     """The N > 1 step under the step plan (semseg_amd/plan.py): C segments between the collectives, the SyncBN exchanges and
     the gradient-bucket all-reduces re-issued as host operations in the recorded order.  Six steps on two ranks (2 eager, 2
     recorded, 2 replayed) against the same six steps sequenced launch by launch (SEMSEG_STEP_PLAN=0): the replicas of the
@@ -174,7 +175,7 @@ def test_two_ranks_replayed_step_plan(report):
     res = {}
     for mode in ("0", "1"):
         tmp = tempfile.mkdtemp(prefix="semseg_plan_dist%s_" % mode)
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", STEPS="6", LR="1e-4", SEMSEG_STEP_PLAN=mode, SEMSEG_SYNCBN_XCHG="0")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", STEPS="6", LR="1e-4", SEMSEG_STEP_PLAN=mode, SEMSEG_SYNCBN_XCHG=xchg)
         subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, tmp],
                               env=env, timeout=900)
@@ -183,13 +184,18 @@ def test_two_ranks_replayed_step_plan(report):
     log = str(p0["plan_log"])
     assert "recorded:" in log and "host operations" in log, log
     nhost = int(log.split("segments, ")[1].split(" host")[0])
-    assert nhost >= int(p0["ncoll"]) + 2, log           # every SyncBN exchange + the gradient buckets + the wait before SGD
+    if xchg == "0":
+        assert nhost >= int(p0["ncoll"]) + 2, log       # every SyncBN exchange (c10d) + the gradient buckets + the wait before SGD
+    else:
+        # the peer-memory exchange is a recorded launch (its exchange number lives in device memory): only the gradient buckets
+        # and the wait before SGD are host operations
+        assert 2 <= nhost <= 16, log
     assert np.array_equal(p0["w"], p1["w"]) and np.array_equal(p0["rv"], p1["rv"]) and np.array_equal(p0["rm"], p1["rm"])
     e0 = res["0"][0]
     e_first = np.abs(p0["losses"][:1] - e0["losses"][:1]).max()
     e_loss = np.abs(p0["losses"] - e0["losses"]).max(axis=1) / np.abs(e0["losses"]).max()
-    report("2-rank step plan (%s) vs launch-by-launch, lr 1e-4: replicas bit-identical after 2 replayed steps; losses per step %s"
-           % (log, " ".join("%.1e" % v for v in e_loss)))
+    report("2-rank step plan, SyncBN through %s (%s) vs launch-by-launch, lr 1e-4: replicas bit-identical after 2 replayed steps; "
+           "losses per step %s" % ("c10d" if xchg == "0" else "the peer-memory exchange", log, " ".join("%.1e" % v for v in e_loss)))
     assert "verified" in log
     assert e_first == 0.0 and e_loss.max() < 5e-2
 
