@@ -278,6 +278,9 @@ def trainer_leg(args, dev, world, rank, B, steps, warmup, arith, kernel_timing, 
         out = {"sec": dt / steps, "loss": float(main_loss.item()), "arith": arith}
         # who sequenced the launches of the timed steps: the C-side replay of a recorded step (csrc/plan.hip) or Python
         replayed = sum(getattr(e, "_plan_replays", 0) for e in tr.engines.values())
+        if dist_on:      # which SyncBN exchange the job took, and why (peer-memory kernel after its start-up self-test, or RCCL)
+            from semseg_amd import syncbn_xchg
+            out["syncbn_exchange"] = syncbn_xchg.DECISION.get(dev.index, (None, "no SyncBN exchange was issued"))[1]
         out["step_driver"] = {"timed_steps_replayed_from_C": min(replayed, steps), "hip_graph": bool(tr.use_graph),
                               "log": tr.plan_log[-1:] if tr.use_plan else ["SEMSEG_STEP_PLAN=0: launch by launch from Python"]}
         for e in tr.engines.values():
@@ -433,6 +436,7 @@ def main():
                                 "SEMSEG_ARITH_F32: exact fp32 products on v_mfma_f32_32x32x2_f32",
                        "two_stream_backward": leg.get("two_stream_backward"),
                        "step_driver": leg.get("step_driver"),
+                       "syncbn_exchange": leg.get("syncbn_exchange", "single process: no exchange"),
                        "tile_table": _tile_summary()},
             "final_main_loss": round(loss_val, 5),
             # direct-convolution FLOPs of the step (SURVEY.md section 8d / BASELINE.md section 4: 3 x forward - first conv's

@@ -338,6 +338,18 @@ class Engine:
         # eager path, advanced by Trainer before every replay of a recorded step (semseg_step_state_set)
         self.drop_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.recorder = None   # semseg_amd.plan.StepPlan while Trainer records a step of this engine
+        # step-plan state, owned by Trainer (semseg_amd/trainer.py): the accepted record and its outputs, the candidate waiting for
+        # the next step's record, the staging buffers the record points at, counters
+        self._plan = None
+        self._plan_candidate = None
+        self._plan_out = None
+        self._plan_x = self._plan_y = None
+        self._plan_eager = 0       # launch-by-launch steps this engine has run under a plan-enabled Trainer
+        self._plan_replays = 0
+        self._plan_drops = 0       # dropout mask draws per step
+        self._plan_gen = -1        # ARENA_GEN at record time
+        self._plan_tries = 0
+        self._plan_off = False     # three recordings failed: the engine stays on the launch-by-launch path
         self.tape_hook = None  # callable(TapeOp) that must call op.fn(); set by tests only
         self._groups = {}
         self.syncbn_collectives_per_step = 0   # SyncBN all-reduces issued by the last forward + backward

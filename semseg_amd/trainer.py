@@ -145,8 +145,8 @@ class Trainer:
         e = self.engine(x)
         if e.params_stale():
             raise RuntimeError("the module tree changed after the Trainer built its engine; build a new Trainer")
-        if not (self.use_plan and e.ktimer is None and e.tape_hook is None and not getattr(e, "_plan_off", False)):
-            if getattr(e, "_plan_replays", 0):
+        if not (self.use_plan and e.ktimer is None and e.tape_hook is None and not e._plan_off):
+            if e._plan_replays:
                 self._set_step_state(e, lr, 0)      # the device part of the dropout counter belongs to replayed steps only
             return self._step_eager(e, x, y, lr)
         # planned steps (the eager ones before the recording included) run on one stream of their own: a recorded stream handle
@@ -204,7 +204,7 @@ class Trainer:
                                                  e.drop_dev.data_ptr(), int(drop_offset), ops._stream()), "step_state_set")
 
     def _step_planned(self, e, x, y, lr, st):
-        plan = getattr(e, "_plan", None)
+        plan = e._plan
         if plan is not None and e._plan_gen != _engine.ARENA_GEN[0]:
             plan = e._plan = None             # a process-wide arena the plan points into was replaced: record again
             self.plan_log.append("discarded: arena generation moved")
@@ -229,7 +229,7 @@ class Trainer:
             e._plan_replays = k
             self.steps += 1
             return e._plan_out
-        n = getattr(e, "_plan_eager", 0)
+        n = e._plan_eager
         if n < EAGER_STEPS or self.steps == 0:
             e._plan_eager = n + 1
             self._set_step_state(e, lr, 0)
@@ -237,7 +237,7 @@ class Trainer:
         return self._record(e, x, y, lr, st)
 
     def _record(self, e, x, y, lr, st):
-        if getattr(e, "_plan_x", None) is None:
+        if e._plan_x is None:
             e._plan_x = torch.empty_like(x, memory_format=torch.contiguous_format)
             e._plan_y = torch.empty_like(y, memory_format=torch.contiguous_format)
         e._plan_x.copy_(x)
@@ -256,7 +256,7 @@ class Trainer:
         if why is None and torch.cuda.memory_stats(self.device).get("allocation.all.allocated", 0) != allocs0:
             why = "device memory was allocated while the step was recorded (a buffer address in the plan may be temporary)"
         if why is not None:
-            e._plan_tries = getattr(e, "_plan_tries", 0) + 1
+            e._plan_tries += 1
             self.plan_log.append("recording failed: " + why)
             if e._plan_tries >= 3:
                 e._plan_off = True
@@ -264,7 +264,7 @@ class Trainer:
                 warnings.warn("semseg_amd.Trainer: the step could not be recorded (%s); it stays on the launch-by-launch path" % why)
             return out
         e._plan_drops = e._drop_calls - drops0
-        prev = getattr(e, "_plan_candidate", None)
+        prev = e._plan_candidate
         if prev is None or prev[1] != _engine.ARENA_GEN[0]:
             e._plan_candidate = (plan, _engine.ARENA_GEN[0])     # accepted when the next step records the same calls
             self.plan_log.append("candidate: %d launches, %d host operations" % (plan.launches(), plan.host_ops()))
@@ -272,7 +272,7 @@ class Trainer:
         e._plan_candidate = None
         diff = prev[0].same_as(plan, ignore=("semseg_dropout2d_mask", 4))
         if diff is not None:
-            e._plan_tries = getattr(e, "_plan_tries", 0) + 1
+            e._plan_tries += 1
             self.plan_log.append("recording failed: two consecutive steps issued different launch sequences: " + diff)
             if e._plan_tries >= 3:
                 e._plan_off = True
