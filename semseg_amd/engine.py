@@ -136,6 +136,7 @@ WINO_BF16X3_KERNEL = os.environ.get("SEMSEG_WINO_GEMM", "standalone")
 # of the bit mask bn_apply writes next to it
 RELU_BITS = os.environ.get("SEMSEG_RELU_BITS", "1") != "0"
 XCHG_HOST_OP = os.environ.get("SEMSEG_XCHG_HOST_OP", "0") == "1"
+WGRAD_EXACT_1X1_ONLY = os.environ.get("SEMSEG_WGRAD_EXACT_1X1_ONLY", "0") == "1"     # measurement: the long-reduction rule for 1x1 convs only
 WGRAD_BF16X3_MAX_M = int(os.environ.get("SEMSEG_WGRAD_BF16X3_MAX_M", "131072"))   # longer weight-gradient reductions: exact fp32 products
 
 
@@ -587,7 +588,7 @@ class Engine:
         # 119 x 119 (M = 226 576: layer1.0.conv1, layer1.0.downsample.0, layer2.0.conv1) measured 3.6-4.2 x the CPU-fp32
         # recompute's rms error under bf16x3 (criterion 3 x) and 0.8-0.9 x with exact products (profiles/r05_insitu_b16.txt);
         # at M = 57 600 (every layer3 / layer4 / head conv of a batch-16 step) bf16x3 is inside the criterion.
-        ar = cl.arith if y.M <= WGRAD_BF16X3_MAX_M else ops.ARITH_F32
+        ar = cl.arith if (y.M <= WGRAD_BF16X3_MAX_M or (WGRAD_EXACT_1X1_ONLY and cl.R * cl.S > 1)) else ops.ARITH_F32
         ev = self._t0(self._wgrad_family(big, ar, cl.Ci), flops)
         ops.conv_wgrad(x.data, x.ld, dy, y.ld, cl.wgrad, scratch, x.N, x.H, x.W, cl.Ci,
                        cl.Co, cl.R, cl.S, cl.stride, cl.pad, cl.dil, arith=ar)

@@ -110,3 +110,23 @@ def test_two_records_are_compared_call_by_call():
     assert "argument 4" in base.same_as(rec(1, 0.5), ignore=("semseg_host_probe", 1))
     assert "host operations" in base.same_as(rec(1, 0.25, host_op=False))
     assert "entry 2" in base.same_as(rec(1, 0.25, extra=True))
+
+
+def test_syncbn_exchange_mode_and_single_process_decision(monkeypatch):
+    """SEMSEG_SYNCBN_XCHG = auto (default) | 1 | 0; without a process group the decision is RCCL / nothing, with its reason kept."""
+    import torch
+    from semseg_amd import syncbn_xchg as sx
+    monkeypatch.delenv("SEMSEG_SYNCBN_XCHG", raising=False)
+    assert sx.mode() == "auto" and not sx.enabled()
+    monkeypatch.setenv("SEMSEG_SYNCBN_XCHG", "1")
+    assert sx.mode() == "1" and sx.enabled()
+    monkeypatch.setenv("SEMSEG_SYNCBN_XCHG", "bogus")
+    assert sx.mode() == "auto"
+    monkeypatch.setenv("SEMSEG_SYNCBN_XCHG", "0")
+    sx.DECISION.clear()
+    dev = torch.device("cuda", 0)
+    assert sx.active(dev) is None and sx.DECISION[0][1] == "SEMSEG_SYNCBN_XCHG=0"
+    monkeypatch.setenv("SEMSEG_SYNCBN_XCHG", "auto")
+    sx.DECISION.clear()
+    assert sx.active(dev) is None and sx.DECISION[0][1] == "no process group"
+    sx.DECISION.clear()
