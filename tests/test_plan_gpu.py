@@ -1,6 +1,6 @@
 """Step plan on the GPU: a train step recorded once and replayed from C (semseg_plan_replay) — and, single-GPU, from one
 hipGraph — must be the step the launch-by-launch driver runs: tool/train.py:269-276 with a different batch, learning rate
-(poly schedule) and Dropout2d mask every step.  Two eager runs of the same seven steps differ by the run-to-run noise of the
+(poly schedule) and Dropout2d mask every step.  Two eager runs of the same eight steps differ by the run-to-run noise of the
 kernels that merge with fp32 / fp64 atomics; the replayed runs must sit inside 4x that noise (+ 1e-6) on every loss and on the
 final weights.  Also: a plan whose arenas moved is re-recorded, and the kernel-timing path bypasses the plan."""
 import numpy as np
