@@ -14,6 +14,7 @@ dangle), and the caller verifies that torch's allocator handed out no new block 
 """
 import ctypes
 import struct
+import threading
 
 import torch
 
@@ -72,6 +73,7 @@ class StepPlan:
     def begin(self):
         assert lib.recorder is None, "another plan is recording"
         lib.load()
+        self._thread = threading.get_ident()      # only this thread's calls belong to the step (a loader thread's do not)
         lib.recorder = self
         self.recording = True
 
@@ -99,7 +101,7 @@ class StepPlan:
 
         def call(*args):
             rc = f(*args)
-            if rc == 0 and self.error is None:
+            if rc == 0 and self.error is None and threading.get_ident() == self._thread:
                 try:
                     self._record(name, argtypes, args)
                 except PlanError as e:

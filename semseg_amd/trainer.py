@@ -237,6 +237,8 @@ class Trainer:
         return self._record(e, x, y, lr, st)
 
     def _record(self, e, x, y, lr, st):
+        if lib.recorder is not None:        # another Trainer of this process is recording right now: this step runs as it is
+            return self._step_eager(e, x, y, lr)
         if e._plan_x is None:
             e._plan_x = torch.empty_like(x, memory_format=torch.contiguous_format)
             e._plan_y = torch.empty_like(y, memory_format=torch.contiguous_format)

@@ -130,3 +130,22 @@ def test_syncbn_exchange_mode_and_single_process_decision(monkeypatch):
     sx.DECISION.clear()
     assert sx.active(dev) is None and sx.DECISION[0][1] == "no process group"
     sx.DECISION.clear()
+
+
+def test_only_the_recording_thread_is_recorded():
+    """Calls another thread makes through the same library while a step is being recorded (a loader thread, an eval engine) are
+    executed and NOT appended."""
+    import threading
+    from semseg_amd._lib import lib
+    from semseg_amd.plan import StepPlan
+    out = (ctypes.c_ulonglong * 7)()
+    addr = ctypes.addressof(out)
+    plan = StepPlan()
+    plan.begin()
+    lib.semseg_host_probe(addr, 1, 2, 3, 0.0, 0.0, None)
+    t = threading.Thread(target=lambda: lib.semseg_host_probe(addr, 9, 9, 9, 0.0, 0.0, None))
+    t.start()
+    t.join()
+    lib.semseg_host_probe(addr, 4, 5, 6, 0.0, 0.0, None)
+    assert plan.end() is None
+    assert out[6] == 3 and plan.launches() == 2
