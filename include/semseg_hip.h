@@ -380,10 +380,12 @@ int semseg_dropout2d_mask(float* mask, int n, float p, unsigned long long seed, 
                           const unsigned long long* offset_dev, hipStream_t stream);   /* offset_dev (optional): offset += *offset_dev, read on the device */
 int semseg_memset_zero(void* ptr, size_t bytes, hipStream_t stream);
 
-/* ---- torch.optim.SGD step (tool/train.py:140,276) over a flat range. */
+/* ---- torch.optim.SGD step (tool/train.py:140,276) over a flat range.  skip_dev (may be NULL): a device int; when it is
+ * non-zero at execution time the launch leaves w and mom untouched (the error flag of semseg_xchg_allreduce_f64: a step
+ * whose SyncBN statistics timed out must not reach the weights). */
 int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, float lr, const float* lr_dev,
                     float momentum, float weight_decay, float grad_scale, int first_step,
-                    hipStream_t stream);
+                    const int* skip_dev, hipStream_t stream);
 
 /* ---- Step plan: launch sequencing below the C ABI (csrc/plan.hip).  The loop body of the reference's train step
  * (tool/train.py:269-276: model(input, target), loss, zero_grad, backward, optimizer.step) is ~1 200 launches of the entry
@@ -421,7 +423,7 @@ int semseg_stream_wait_stream(hipStream_t waiter, hipStream_t signaller);
 int semseg_step_state_set(float* lr_dev2, float lr, float lr_head, unsigned long long* drop_dev,
                           unsigned long long drop_offset, hipStream_t stream);
 /* semseg_step_state_set + the copies of the caller's batch (x) and targets (y) into the buffers the record points at, in ONE
- * launch (any byte counts; 16-byte aligned addresses). */
+ * launch (any byte counts, any alignment: 16-byte aligned pairs are copied in 16-byte words, 4-byte aligned ones in dwords). */
 int semseg_step_begin(void* x_dst, const void* x_src, size_t x_bytes, void* y_dst, const void* y_src, size_t y_bytes,
                       float* lr_dev2, float lr, float lr_head, unsigned long long* drop_dev, unsigned long long drop_offset,
                       hipStream_t stream);

@@ -8,7 +8,8 @@ namespace {
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                   float* __restrict__ m, size_t n, float lr,
                                                   const float* lr_ptr, float momentum, float wd,
-                                                  float gscale, int first) {
+                                                  float gscale, int first, const int* __restrict__ skip) {
+  if (skip && skip[0]) return;      // the step's statistics are known to be garbage (timed-out SyncBN exchange): leave the weights
   if (lr_ptr) lr = lr_ptr[0];
   const size_t n4 = n >> 2;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -61,7 +62,7 @@ extern "C" int semseg_memset_zero(void* ptr, size_t bytes, hipStream_t stream) {
 
 extern "C" int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, float lr,
                                const float* lr_dev, float momentum, float weight_decay,
-                               float grad_scale, int first_step, hipStream_t stream) {
+                               float grad_scale, int first_step, const int* skip_dev, hipStream_t stream) {
   if (!w || !g || !mom || ((uintptr_t)w & 15) || ((uintptr_t)g & 15) || ((uintptr_t)mom & 15))
     return SEMSEG_EINVAL;
   if (n == 0) return SEMSEG_OK;
@@ -69,6 +70,6 @@ extern "C" int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, f
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
   sgd_kernel<<<(int)grid, 256, 0, stream>>>(w, g, mom, n, lr, lr_dev, momentum, weight_decay,
-                                            grad_scale, first_step);
+                                            grad_scale, first_step, skip_dev);
   return semseg_launch_status();
 }

@@ -123,7 +123,23 @@ __global__ void step_state_kernel(float* lr2, float lr, float lr_head, unsigned 
 }
 
 // One launch in front of a replayed step: the caller's input batch and targets into the buffers the record points at (any
-// byte count; 16-byte body + byte tail) and the per-step values into device memory.
+// byte count; 16-byte body + byte tail) and the per-step values into device memory.  A source / destination pair that is not
+// 16-byte aligned (a contiguous slice of a larger device batch: 3 * 473 * 473 * 4 bytes per image is 12 mod 16) is copied in
+// dwords, one that is not even 4-byte aligned in bytes: the eager path has no alignment requirement either.
+__device__ __forceinline__ void copy_any(unsigned char* d, const unsigned char* s, size_t nb, size_t tid, size_t nth) {
+  const uintptr_t a = (uintptr_t)d | (uintptr_t)s;
+  if ((a & 15) == 0) {
+    const size_t n16 = nb >> 4;
+    for (size_t i = tid; i < n16; i += nth) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    for (size_t i = (n16 << 4) + tid; i < nb; i += nth) d[i] = s[i];
+  } else if ((a & 3) == 0) {
+    const size_t n4 = nb >> 2;
+    for (size_t i = tid; i < n4; i += nth) reinterpret_cast<uint32_t*>(d)[i] = reinterpret_cast<const uint32_t*>(s)[i];
+    for (size_t i = (n4 << 2) + tid; i < nb; i += nth) d[i] = s[i];
+  } else {
+    for (size_t i = tid; i < nb; i += nth) d[i] = s[i];
+  }
+}
 __global__ __launch_bounds__(256) void step_begin_kernel(unsigned char* xd, const unsigned char* xs, size_t xb, unsigned char* yd,
                                                          const unsigned char* ys, size_t yb, float* lr2, float lr, float lr_head,
                                                          unsigned long long* drop, unsigned long long off) {
@@ -135,11 +151,8 @@ __global__ __launch_bounds__(256) void step_begin_kernel(unsigned char* xd, cons
     }
     if (drop) drop[0] = off;
   }
-  const size_t x16 = xb >> 4, y16 = yb >> 4;
-  for (size_t i = tid; i < x16; i += nth) reinterpret_cast<uint4*>(xd)[i] = reinterpret_cast<const uint4*>(xs)[i];
-  for (size_t i = tid; i < y16; i += nth) reinterpret_cast<uint4*>(yd)[i] = reinterpret_cast<const uint4*>(ys)[i];
-  for (size_t i = (x16 << 4) + tid; i < xb; i += nth) xd[i] = xs[i];
-  for (size_t i = (y16 << 4) + tid; i < yb; i += nth) yd[i] = ys[i];
+  copy_any(xd, xs, xb, tid, nth);
+  copy_any(yd, ys, yb, tid, nth);
 }
 
 }  // namespace
@@ -327,7 +340,6 @@ int semseg_step_begin(void* x_dst, const void* x_src, size_t x_bytes, void* y_ds
                       float* lr_dev2, float lr, float lr_head, unsigned long long* drop_dev, unsigned long long drop_offset,
                       hipStream_t stream) {
   if ((x_bytes && (!x_dst || !x_src)) || (y_bytes && (!y_dst || !y_src))) return SEMSEG_EINVAL;
-  if ((((uintptr_t)x_dst | (uintptr_t)x_src | (uintptr_t)y_dst | (uintptr_t)y_src) & 15) != 0) return SEMSEG_EINVAL;
   const size_t chunks = ((x_bytes > y_bytes ? x_bytes : y_bytes) >> 4) + 1;
   size_t grid = (chunks + 255) / 256;
   if (grid > 2048) grid = 2048;

@@ -348,6 +348,8 @@ class Engine:
         self._plan_eager = 0       # launch-by-launch steps this engine has run under a plan-enabled Trainer
         self._plan_replays = 0
         self._plan_drops = 0       # dropout mask draws per step
+        self._plan_drop_base = 0   # host dropout counter in front of the accepted record
+        self._plan_sig = None      # Trainer._host_signature at record time
         self._plan_gen = -1        # ARENA_GEN at record time
         self._plan_tries = 0
         self._plan_off = False     # three recordings failed: the engine stays on the launch-by-launch path
@@ -1196,7 +1198,12 @@ class Engine:
         lse = self.buf((N, H, W), tag="lse" + tag)
         pred = self.buf((N, H, W), dtype=torch.int64, tag="pred" + tag) if want_pred else None
         acc = self.buf((3,), dtype=F64, tag="acc" + tag)
-        loss = self.buf((1,), tag="loss" + tag)
+        # both losses sit in ONE [2] buffer: what the callers see are slices of a clone of it (one launch per step, Trainer.step /
+        # module_base._NetFunction), so a loss tensor kept across steps keeps its value — the reference returns fresh tensors
+        # (model/pspnet.py:101-103)
+        if tag == "m":
+            self._losses = self.buf((2,), tag="losses")
+        loss = self._losses[0:1] if tag == "m" else self._losses[1:2]
         ops.ce_head_fwd(scores.data, scores.ld, label, lse, pred, acc, loss, N, scores.H, scores.W, H, W,
                         scores.C, ignore_index)
         rec = dict(scores=scores, label=label, lse=lse, acc=acc, H=H, W=W, ignore=ignore_index)

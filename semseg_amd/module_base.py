@@ -23,8 +23,10 @@ class _NetFunction(torch.autograd.Function):
         pred, main_loss, aux_loss = engine.forward_train(x, y, ignore_index)
         ctx.engine = engine
         ctx.mark_non_differentiable(pred)
-        # 0-dim views, like nn.CrossEntropyLoss returns
-        return pred, main_loss.view(()), aux_loss.view(())
+        # 0-dim tensors, like nn.CrossEntropyLoss returns — fresh ones (the engine's own loss buffer is rewritten by the next
+        # forward; `losses.append(main_loss)` in a caller's loop must keep every step's value, as with the reference).  `pred`
+        # stays the engine's buffer (1.8 MB per image at 473 x 473): valid until the next forward of this engine, .clone() to keep.
+        return pred, main_loss.clone().view(()), aux_loss.clone().view(())
 
     @staticmethod
     def backward(ctx, _gpred, gmain, gaux):

@@ -557,9 +557,9 @@ def label_check(label, C, ignore_index):
     return int(bad.item())
 
 
-def sgd_step(w, g, mom, n, lr, momentum, weight_decay, grad_scale=1.0, first_step=False, lr_dev=None):
+def sgd_step(w, g, mom, n, lr, momentum, weight_decay, grad_scale=1.0, first_step=False, lr_dev=None, skip_dev=None):
     _ck(lib.semseg_sgd_step(_p(w), _p(g), _p(mom), n, float(lr), _p(lr_dev), momentum, weight_decay,
-                            grad_scale, int(first_step), _stream()), "sgd_step")
+                            grad_scale, int(first_step), _p(skip_dev), _stream()), "sgd_step")
 
 
 def psamask_forward(psa_type, inp, out, num, fH, fW, mH, mW, hH, hW):

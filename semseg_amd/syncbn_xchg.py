@@ -3,7 +3,9 @@ nn.SyncBatchNorm all-reduces once per layer and pass (tool/train.py:142) travel 
 memory — every rank writes its vector into a slot of every peer's buffer and sums the slots of its own — in ONE kernel
 per rank, with no c10d call and no host involvement.  torch.distributed is used once, to hand the IPC handles round.
 
-SEMSEG_SYNCBN_XCHG = auto (default) | 1 | 0.
+SEMSEG_SYNCBN_XCHG = 0 (default) | auto | 1.
+  0     RCCL (`dist.all_reduce`).  The default since round 6: the exchange has never run across xGMI, so a job only
+        takes it when asked to.
   auto  on a multi-rank one-node job the exchange is built and SELF-TESTED among the real peers at the first SyncBN
         collective (`active()`): 64 exchanges of known vectors of the sizes the engine uses, 2 s bound per exchange, every
         rank checks every result, and the ranks agree on the verdict (MIN all-reduce).  Passed: the training step uses the
@@ -11,9 +13,11 @@ SEMSEG_SYNCBN_XCHG = auto (default) | 1 | 0.
         hosts, world > 8 or world == 1 — and every rank uses RCCL (`dist.all_reduce`), with the reason kept in `DECISION`.
         The path has only ever run with several processes on ONE GPU (tests/test_dist_gpu.py); the self-test is what
         stands between it and the first multi-GPU run.
+        In training the wait for a peer's flag is then bounded by TRAIN_TIMEOUT_MS (10 minutes, the order of RCCL's own
+        watchdog: a rank that saves a checkpoint or logs validation arrives late, not never), not by the kernel's 20 s default.
   1     forced (tests, the forced one-rank bench line); no self-test.
-  0     RCCL.
-A timed-out exchange is not silent: Trainer.step polls the error flag through a pinned ring after every step
+A timed-out exchange is not silent, and it does not reach the weights: both SGD launches of the step read the error flag on the
+device and do nothing when it is set (semseg_sgd_step's skip_dev; running statistics of that step ARE garbage). Trainer.step polls the error flag through a pinned ring after every step
 (`watch` / `poll`), Trainer.check_labels() and `check()` block and raise."""
 import atexit
 import ctypes
@@ -30,9 +34,12 @@ _INSTANCES = {}
 DECISION = {}            # device index -> (exchange or None, reason)
 
 
+TRAIN_TIMEOUT_MS = 600000
+
+
 def mode():
-    v = os.environ.get("SEMSEG_SYNCBN_XCHG", "auto")
-    return v if v in ("0", "1", "auto") else "auto"
+    v = os.environ.get("SEMSEG_SYNCBN_XCHG", "0")
+    return v if v in ("0", "1", "auto") else "0"
 
 
 def enabled():
@@ -93,6 +100,7 @@ def _auto(device):
         x.close()
         return None, "auto: self-test failed" + (": " + why if why else " on a peer")
     _INSTANCES[(device.index, id(None))] = x
+    x.timeout_ms = TRAIN_TIMEOUT_MS
     return x, "auto: self-test passed on %d ranks" % world
 
 

@@ -148,18 +148,27 @@ class Trainer:
         if not (self.use_plan and e.ktimer is None and e.tape_hook is None and not e._plan_off):
             if e._plan_replays:
                 self._set_step_state(e, lr, 0)      # the device part of the dropout counter belongs to replayed steps only
-            return self._step_eager(e, x, y, lr)
+            return self._fresh(e, self._step_eager(e, x, y, lr))
         # planned steps (the eager ones before the recording included) run on one stream of their own: a recorded stream handle
         # must mean the same stream at every replay, and a graph cannot be captured on the default stream
         cur = torch.cuda.current_stream()
         if os.environ.get("SEMSEG_PLAN_OWN_STREAM", "1") == "0" and not self.use_graph:      # A/B only
-            return self._step_planned(e, x, y, lr, cur)
+            return self._fresh(e, self._step_planned(e, x, y, lr, cur))
         st = _engine._shared(self.device, "plan_stream", lambda: torch.cuda.Stream(device=self.device))
         ops.stream_wait(st, cur)
         with torch.cuda.stream(st):
             out = self._step_planned(e, x, y, lr, st)
         ops.stream_wait(cur, st)
-        return out
+        return self._fresh(e, out)
+
+    @staticmethod
+    def _fresh(e, out):
+        """(pred, main_loss, aux_loss) as the caller gets them: the two losses are slices of a CLONE of the engine's [2] loss buffer
+        (one 8-byte copy on the caller's stream), so a loss kept across steps keeps its value like the fresh tensors the
+        reference returns (model/pspnet.py:101-103, `losses.append(main_loss)`); `pred` IS the engine's buffer — valid until
+        the next step of this engine, `.clone()` to keep ("Output lifetime")."""
+        l = e._losses.clone()
+        return out[0], l[0:1], l[1:2]
 
     def _step_eager(self, e, x, y, lr, lr_dev=None):
         pred, main_loss, aux_loss = e.forward_train(x, y, self.ignore_index)
@@ -172,14 +181,22 @@ class Trainer:
             e.host_op(lambda: [w.wait() for w in e._works])
         first = self.steps == 0
         gs = 1.0 / self.world
+        # a step whose SyncBN statistics came from a timed-out peer-memory exchange must not reach the weights: both SGD launches read
+        # the exchange's error flag on the device and leave w / momentum untouched when it is set (the host raises at most RING steps
+        # later, _watch_exchange; every exchange after a time-out gives up at once, so the flag stays set until reset())
+        skip = None
+        if self.dist_on:
+            from . import syncbn_xchg
+            xc = syncbn_xchg.DECISION.get(self.device.index, (None,))[0]
+            skip = None if xc is None else xc.err
         # a recorded step reads both learning rates from device memory (semseg_step_state_set); the by-value argument is then
         # unused and kept at 0 so that two records of consecutive steps of a schedule hold the same calls
         ops.sgd_step(self.flat_w, e.flat_grad, self.flat_m, self.split, lr if lr_dev is None else 0.0, self.momentum, self.wd,
-                     gs, first, lr_dev=None if lr_dev is None else lr_dev[0:1])
+                     gs, first, lr_dev=None if lr_dev is None else lr_dev[0:1], skip_dev=skip)
         n2 = self.total - self.split
         ops.sgd_step(self.flat_w[self.split:], e.flat_grad[self.split:], self.flat_m[self.split:], n2,
                      lr * 10.0 if lr_dev is None else 0.0, self.momentum, self.wd, gs, first,
-                     lr_dev=None if lr_dev is None else lr_dev[1:2])
+                     lr_dev=None if lr_dev is None else lr_dev[1:2], skip_dev=skip)
         self.steps += 1
         # label counts of earlier steps that have reached the host by now (non-blocking; see Engine.LabelWatch)
         e._label_watch().poll(self.model.cls[4].weight.shape[0])
@@ -203,20 +220,40 @@ class Trainer:
         ops._ck(lib.raw("semseg_step_state_set")(self._step_state.data_ptr(), float(lr), float(lr) * 10.0,
                                                  e.drop_dev.data_ptr(), int(drop_offset), ops._stream()), "step_state_set")
 
+    def _host_signature(self, e):
+        """Host state that a recorded step bakes into its launch arguments and the launch-by-launch step re-reads every step
+        (ADVICE r5): BatchNorm / Dropout2d training flags and p, momentum, weight decay, ignore_index, the loss weights' buffers,
+        the 1 / world gradient scale.  A replay is only valid while it is unchanged."""
+        from torch import nn
+        if getattr(e, "_sig_mods", None) is None:     # the module tree is fixed while the engine lives (Engine.params_stale)
+            e._sig_mods = [m for m in self.model.modules() if isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.Dropout2d))]
+        mods = tuple((m.training, getattr(m, "p", None), getattr(m, "momentum", None), getattr(m, "eps", None))
+                     for m in e._sig_mods)
+        return (mods, self.momentum, self.wd, self.ignore_index, self.aux_weight, self.world, self.g_main.data_ptr(),
+                self.g_aux.data_ptr())
+
     def _step_planned(self, e, x, y, lr, st):
         plan = e._plan
         if plan is not None and e._plan_gen != _engine.ARENA_GEN[0]:
             plan = e._plan = None             # a process-wide arena the plan points into was replaced: record again
             self.plan_log.append("discarded: arena generation moved")
+        if plan is not None and e._plan_sig != self._host_signature(e):
+            plan = e._plan = None
+            e._plan_candidate = None
+            self.plan_log.append("discarded: host state baked into the record changed (training flags / dropout p / momentum / "
+                                 "weight decay / ignore_index / world)")
         if plan is not None:
             k = e._plan_replays + 1
+            # the recorded dropout launches carry the host counter of the RECORDED step by value; the device part makes up the
+            # difference to where the host counter stands now (eager steps interleaved with replays advance it too: ADVICE r5)
+            drop_off = e._drop_calls - e._plan_drop_base
             # one launch: the caller's batch into the recorded input buffers + this step's learning rates / dropout counter
             xs, ys = x.contiguous(), y.contiguous()
             assert xs.dtype == e._plan_x.dtype and ys.dtype == e._plan_y.dtype and xs.shape == e._plan_x.shape and ys.shape == e._plan_y.shape
             ops._ck(lib.raw("semseg_step_begin")(e._plan_x.data_ptr(), xs.data_ptr(), xs.numel() * xs.element_size(),
                                                  e._plan_y.data_ptr(), ys.data_ptr(), ys.numel() * ys.element_size(),
                                                  self._step_state.data_ptr(), float(lr), float(lr) * 10.0,
-                                                 e.drop_dev.data_ptr(), int(k * e._plan_drops), ops._stream()), "step_begin")
+                                                 e.drop_dev.data_ptr(), int(drop_off), ops._stream()), "step_begin")
             e._drop_calls += e._plan_drops
             if self.dist_on:
                 e._works = []
@@ -238,6 +275,7 @@ class Trainer:
 
     def _record(self, e, x, y, lr, st):
         if lib.recorder is not None:        # another Trainer of this process is recording right now: this step runs as it is
+            self._set_step_state(e, lr, 0)
             return self._step_eager(e, x, y, lr)
         if e._plan_x is None:
             e._plan_x = torch.empty_like(x, memory_format=torch.contiguous_format)
@@ -246,6 +284,7 @@ class Trainer:
         e._plan_y.copy_(y)
         self._set_step_state(e, lr, 0)
         plan = StepPlan()
+        sig = self._host_signature(e)
         drops0 = e._drop_calls
         allocs0 = torch.cuda.memory_stats(self.device).get("allocation.all.allocated", 0)
         e.recorder = plan
@@ -283,6 +322,8 @@ class Trainer:
             return out
         e._plan, e._plan_out, e._plan_replays = plan, out, 0
         e._plan_gen = _engine.ARENA_GEN[0]
+        e._plan_drop_base = drops0          # host dropout counter in front of the accepted record
+        e._plan_sig = sig
         msg = "recorded: %d launches in %d segments, %d host operations; verified against the previous step's record" % (
             plan.launches(), len(plan.segments) - plan.host_ops(), plan.host_ops())
         if self.use_graph and plan.host_ops() == 0:

@@ -11,7 +11,11 @@ reference (/root/reference, imported here on CPU):
                                 restated from their formula there, that part stays "parity unpinned")
 
 Run in the build container only (needs ~50 GB of RAM for the batch-16 step):
-    python tests/golden/make_golden_headline.py [train] [ms] [psa]
+    python tests/golden/make_golden_headline.py [train] [ms] [psa] [psp50]
+
+  pspnet50_c150_s473_b16.npz    BASELINE configs[1] at its stated batch (round 6): PSPNet-50, 473x473, 150 classes, BATCH 16
+                                train step (model/pspnet.py:30-105): same contents plus sampled gradients of the last
+                                dilated conv of layer3 and layer4
 
   psanet101_c150_s465_b16.npz   BASELINE configs[3] at its stated size: PSANet-101, 465x465, 150 classes, psa_type 2,
                                 shrink 2, full 59x59 mask, BATCH 16 train step (model/psanet.py:154-179): same contents
@@ -46,11 +50,11 @@ PSA_CFG = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=59, mask_w=59,
                psa_softmax=True)
 
 
-def train_fixture(rp, segnet, arch="psp"):
-    layers, classes, batch = 101, 150, 16
+def train_fixture(rp, segnet, arch="psp", layers=101):
+    classes, batch = 150, 16
     size = 473 if arch == "psp" else 465
     psa_cfg = None if arch == "psp" else PSA_CFG
-    out_name = "pspnet101_c150_s473_b16.npz" if arch == "psp" else "psanet101_c150_s465_b16.npz"
+    out_name = "pspnet%d_c150_s473_b16.npz" % layers if arch == "psp" else "psanet101_c150_s465_b16.npz"
     if arch == "psp":
         m = rp.PSPNet(layers=layers, classes=classes, zoom_factor=8, dropout=0.0, pretrained=False)
     else:
@@ -66,8 +70,8 @@ def train_fixture(rp, segnet, arch="psp"):
     pred, ml, al = m(x, y)
     hook.remove()
     (ml + 0.4 * al).backward()
-    print("reference %s-101 %d^2 batch 16 train step on the CPU: %.1f s, main %.6f aux %.6f"
-          % ("PSPNet" if arch == "psp" else "PSANet", size, time.time() - t0, ml.item(), al.item()), flush=True)
+    print("reference %s-%d %d^2 batch 16 train step on the CPU: %.1f s, main %.6f aux %.6f"
+          % ("PSPNet" if arch == "psp" else "PSANet", layers, size, time.time() - t0, ml.item(), al.item()), flush=True)
     grads = {k: p.grad.clone() for k, p in m.named_parameters()}
     new_sd = {k: v.clone() for k, v in m.state_dict().items()}
     # top-2 margin of the reference's own upsampled train-mode scores at the sampled pixels, relative to max |score|: an
@@ -89,11 +93,13 @@ def train_fixture(rp, segnet, arch="psp"):
     fx["gnorm"] = np.array([grads[k].double().norm().item() for k in names])
     head = ["cls.4.weight", "cls.4.bias", "aux.4.weight", "aux.4.bias", "layer0.1.weight", "layer0.1.bias"]
     bufs = ["layer0.1.running_mean", "layer0.1.running_var", "layer4.2.bn3.running_var", "cls.1.running_mean"]
+    if layers == 50:   # configs[1]: also the stored gradient of one dilated conv of each of layer3 / layer4 (sampled)
+        head += ["layer3.5.conv2.weight", "layer4.2.conv2.weight"]
     if arch == "psa":   # the PSA module's own last layers (model/psanet.py:29-51) and one of its BatchNorms
         head += ["psa.proj.0.weight", "psa.attention.3.weight", "psa.attention_p.3.weight"]
         bufs += ["psa.proj.1.running_var"]
     for k in head:
-        if grads[k].numel() > (1 << 20):   # the PSA module's big 1x1 weights: a [::8, ::8] sample and the full maximum
+        if grads[k].numel() > (1 << 19):   # the big weights: a [::8, ::8] sample and the full maximum
             fx["gradsub/" + k] = grads[k].numpy()[::8, ::8].copy()
             fx["gradmax/" + k] = np.float64(grads[k].abs().max().item())
         else:
@@ -172,6 +178,8 @@ def main():
         train_fixture(rp, segnet)
     if "psa" in what:
         train_fixture(rpa, segnet, arch="psa")
+    if "psp50" in what:
+        train_fixture(rp, segnet, layers=50)
 
 
 if __name__ == "__main__":

@@ -105,6 +105,40 @@ def test_insitu_pspnet101_473_batch16_sampled(arith, report):
     assert any(r[0] == "stem" for r in chk.rows) and any(r[0] == "ce" for r in chk.rows)
 
 
+# the sharp criterion at the headline batch belongs in the suite the driver runs.  The ops where batch 16
+# differs in kind from batch 2: the two K = 36 864 / 9 216 Winograd head convs, all of layer4 (dilation 4), three of layer3's
+# 23 blocks, and the three 1x1 weight gradients over 226 576 pixels that round 5 found at 3.5-5.1 x under bf16x3
+# (Engine WGRAD_BF16X3_MAX_M).  Only module ops (the non-module ones — CE heads, max pool, pool / upsample adjoints — do not
+# change in kind with the batch and cost minutes of fp64 at 16 x 150 x 473 x 473; the opt-in run above keeps them).
+B16_DEFAULT = ("cls.0", "cls.1", "aux.0", "aux.1", "layer4.", "layer3.0.", "layer3.11.", "layer3.22.", "layer1.0.conv1",
+               "layer1.0.downsample.0", "layer2.0.conv1")
+
+
+@pytest.mark.skipif(os.environ.get("SEMSEG_SKIP_BIG_INSITU") == "1", reason="big in-situ cases disabled")
+def test_insitu_pspnet101_473_batch16_default_subset(arith, report):
+    """The per-op criterion at the HEADLINE batch (16) in the default GPU suite, both arithmetics, same bounds as at batch 2."""
+    chk = _case(report, "pspnet101 c150 473^2 b16 DEFAULT SUBSET [%s]" % arith, "psp", 101, 150, 473, 16, oracle_loss=False,
+                only=lambda kind, name: name is not None and name.startswith(B16_DEFAULT))
+    names = {r[1] for r in chk.rows}
+    assert {"cls.0", "aux.0", "layer4.2.conv2", "layer3.11.conv2", "layer1.0.conv1", "layer1.0.downsample.0",
+            "layer2.0.conv1"} <= names, names
+    assert sum(1 for r in chk.rows if r[2] == "wgrad-wino") == 8      # cls.0, aux.0, layer4 x 3, layer3 x 3
+    assert sum(1 for r in chk.rows if r[2].startswith("dgrad+bnr")) >= 10
+
+
+@pytest.mark.skipif(os.environ.get("SEMSEG_INSITU_B16") != "1",
+                    reason="opt-in (SEMSEG_INSITU_B16=1): ~10 min of CPU fp64 recomputation at batch 16")
+def test_insitu_psanet101_465_batch16_sampled(report):
+    """BASELINE configs[3] at its stated batch, per op (run once, table kept: profiles/r06_insitu_psa_b16.txt):
+    the PSA module (every op), layer4, the first / last block of layer3, both heads, the non-module ops."""
+    cfg = dict(psa_type=2, compact=False, shrink_factor=2, mask_h=59, mask_w=59, normalization_factor=1.0,
+               psa_softmax=True)
+    sample = ("psa.", "layer4.", "layer3.0.", "layer3.22.", "cls.", "aux.", "layer0.", "layer1.0.", "layer2.0.")
+    chk = _case(report, "psanet101 c150 465^2 b16 SAMPLED mask59", "psa", 101, 150, 465, 16, psa_cfg=cfg, oracle_loss=False,
+                only=lambda kind, name: name is None or name.startswith(sample))
+    assert "psa" in {r[0] for r in chk.rows}
+
+
 @pytest.mark.skipif(os.environ.get("SEMSEG_SKIP_BIG_INSITU") == "1", reason="big in-situ cases disabled")
 def test_insitu_psanet101_465(report):
     """BASELINE configs[3]: PSANet-101 465x465, 150 classes, full 59x59 mask, batch 2."""

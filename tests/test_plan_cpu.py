@@ -113,15 +113,15 @@ def test_two_records_are_compared_call_by_call():
 
 
 def test_syncbn_exchange_mode_and_single_process_decision(monkeypatch):
-    """SEMSEG_SYNCBN_XCHG = auto (default) | 1 | 0; without a process group the decision is RCCL / nothing, with its reason kept."""
+    """SEMSEG_SYNCBN_XCHG = 0 (default since round 6: opt-in) | auto | 1; without a process group the decision is RCCL / nothing, with its reason kept."""
     import torch
     from semseg_amd import syncbn_xchg as sx
     monkeypatch.delenv("SEMSEG_SYNCBN_XCHG", raising=False)
-    assert sx.mode() == "auto" and not sx.enabled()
+    assert sx.mode() == "0" and not sx.enabled()
     monkeypatch.setenv("SEMSEG_SYNCBN_XCHG", "1")
     assert sx.mode() == "1" and sx.enabled()
     monkeypatch.setenv("SEMSEG_SYNCBN_XCHG", "bogus")
-    assert sx.mode() == "auto"
+    assert sx.mode() == "0"
     monkeypatch.setenv("SEMSEG_SYNCBN_XCHG", "0")
     sx.DECISION.clear()
     dev = torch.device("cuda", 0)

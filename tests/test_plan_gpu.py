@@ -87,3 +87,100 @@ def test_plan_is_rerecorded_when_an_arena_moves_and_bypassed_by_the_kernel_timer
     tr.step(x, y, 0.01)
     assert e._plan_replays == 2
     torch.cuda.synchronize()
+
+
+def test_replay_takes_unaligned_batch_slices_and_notices_changed_host_state():
+    """ADVICE r5: (1) a contiguous slice of a larger device batch is not 16-byte aligned (3 * 73 * 73 * 4 bytes per image = 12 mod 16;
+    the headline 3 * 473 * 473 * 4 likewise): the replayed step must take it like the eager step does; (2) host state that a record
+    bakes in (BatchNorm training flags, Dropout2d p, weight decay) changes -> the plan is discarded and recorded again."""
+    _, _, tr, e = _run("plan")
+    assert e._plan is not None
+    big_x = torch.randn(5, 3, 73, 73).cuda()
+    big_y = torch.randint(0, 21, (5, 73, 73)).cuda()
+    x, y = big_x[1:3], big_y[1:3]
+    assert x.is_contiguous() and x.data_ptr() % 16 != 0
+    n0 = e._plan_replays
+    tr.step(x, y, 0.01)
+    torch.cuda.synchronize()
+    assert e._plan_replays == n0 + 1
+    assert torch.equal(e._plan_x, x) and torch.equal(e._plan_y, y)
+    tr.wd = 5e-4
+    tr.step(x, y, 0.01)
+    assert e._plan is None and any("host state" in l for l in tr.plan_log)
+    tr.step(x, y, 0.01)
+    assert e._plan is not None and e._plan_replays == 0
+    tr.model.cls[3].p = 0.3
+    tr.step(x, y, 0.01)
+    assert e._plan is None
+    torch.cuda.synchronize()
+
+
+def test_dropout_counter_of_replays_follows_the_host_counter():
+    """eager steps interleaved with replays (kernel timer set) advance the host dropout counter; the next replay must
+    not reuse the counter values the eager step consumed — the mask of every step is the mask of its own call number."""
+    from semseg_amd import engine as E
+    from semseg_amd import ops
+    _, _, tr, e = _run("plan")
+    x = torch.randn(2, 3, 73, 73).cuda()
+    y = torch.randint(0, 21, (2, 73, 73)).cuda()
+
+    def mask_of_call(k, n):
+        m = torch.empty(n, device="cuda")
+        ops.dropout2d_mask(m, 0.1, torch.initial_seed(), k, None)
+        return m
+
+    def cls_mask():
+        return [t for (seq, tag), t in e._bufs.items() if tag == "dropmask"][0].reshape(-1).clone()
+
+    tr.step(x, y, 0.01)                # replay
+    torch.cuda.synchronize()
+    c0 = e._drop_calls
+    assert torch.equal(cls_mask(), mask_of_call(c0 - 1, cls_mask().numel()))     # cls drew call c0 - 1, aux call c0
+    e.ktimer = E.KernelTimer()
+    tr.step(x, y, 0.01)                # eager (timed) step in between
+    e.ktimer = None
+    tr.step(x, y, 0.01)                # replay again
+    torch.cuda.synchronize()
+    assert e._drop_calls == c0 + 4
+    assert torch.equal(cls_mask(), mask_of_call(c0 + 3, cls_mask().numel()))
+
+
+def test_output_lifetime_contract():
+    """INTEGRATION.md "Output lifetime" (VERDICT r5 item 6): the two losses a step returns are fresh tensors — a list of them
+    collected over steps keeps every step's value, as with the reference (model/pspnet.py:101-103) — on the Trainer path
+    (eager, recorded and replayed steps) and on the nn.Module path; `pred` is the engine's buffer: documented as valid until the
+    next step, and the test pins that it IS shared, so that the document cannot drift from the code."""
+    from oracle import segnet
+    from model.pspnet import PSPNet
+    from semseg_amd.trainer import Trainer
+    torch.manual_seed(3)
+    m = PSPNet(layers=50, classes=21, zoom_factor=8, dropout=0.1, pretrained=False)
+    m.load_state_dict(segnet.recipe_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234))
+    m = m.cuda().train()
+    tr = Trainer(m, base_lr=0.01, sync_bn=False)
+    g = torch.Generator().manual_seed(2)
+    kept, vals, preds = [], [], []
+    for it in range(7):          # 2 eager + 2 recorded + 3 replayed
+        x = torch.randn(2, 3, 73, 73, generator=g).cuda()
+        y = torch.randint(0, 21, (2, 73, 73), generator=g).cuda()
+        pred, ml, al = tr.step(x, y, 0.01)
+        kept.append((ml, al))
+        vals.append((float(ml.item()), float(al.item())))
+        preds.append(pred)
+    torch.cuda.synchronize()
+    e = next(iter(tr.engines.values()))
+    assert e._plan_replays == 3
+    assert len({v[0] for v in vals}) == 7                                        # the steps really differ
+    assert [(float(a.item()), float(b.item())) for a, b in kept] == vals         # ... and every kept loss kept its value
+    assert len({p.data_ptr() for p in preds}) == 1                               # pred: the engine's buffer, as documented
+    # nn.Module path
+    m2 = PSPNet(layers=50, classes=21, zoom_factor=8, dropout=0.0, pretrained=False).cuda().train()
+    kept, vals = [], []
+    for it in range(3):
+        x = torch.randn(2, 3, 73, 73, generator=g).cuda()
+        y = torch.randint(0, 21, (2, 73, 73), generator=g).cuda()
+        _, ml, al = m2(x, y)
+        (ml + 0.4 * al).backward()
+        kept.append((ml.detach(), al.detach()))
+        vals.append((float(ml.item()), float(al.item())))
+    assert [(float(a.item()), float(b.item())) for a, b in kept] == vals and len({v[0] for v in vals}) == 3
