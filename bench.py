@@ -28,7 +28,19 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 ISO_STEPS = 2
-PMC_FILE = "r05_pmc_per_kernel.json"   # per-kernel HBM bytes / MFMA-busy from the rocprofv3 --pmc passes of this round
+# per-kernel HBM bytes / MFMA-busy from the rocprofv3 --pmc passes of this round, one file per profiled configuration: each file
+# names the workload it was collected on (`workload` = config.workload of the bench line of the same passes) and _attach_pmc only
+# uses a file whose workload IS the running one — bytes of a batch-16 launch say nothing about a batch-2 launch
+PMC_FILES = ("r06_pmc_per_kernel.json", "r06_bs2_pmc_per_kernel.json")
+
+
+def shape_name(size, classes):
+    """Which BASELINE.json dataset shape (size, classes) is, for config.workload."""
+    if classes == 150 and size in (473, 465):
+        return "ADE20K-shape"
+    if classes == 19 and size in (713, 705):
+        return "Cityscapes-shape"
+    return "custom-shape"
 
 
 def conv_flops_per_image(model, size):
@@ -421,10 +433,7 @@ def main():
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "PS%sNet%d ADE20K-shape %dx%d, %d classes, global batch %d (per-GPU %d), "
-                                   "train step fwd+loss+bwd+SGD, SyncBN, random-init weights"
-                                   % ("P" if args.arch == "psp" else "A", args.layers, args.size, args.size,
-                                      args.classes, args.global_batch, B),
+            "config": {"workload": workload_name(args, B),
                        "parallelism": "dp%d" % world,
                        "path": ("semseg_amd.Trainer (fused loop body of tool/train.py:269-276)" if primary_trainer else
                                 "nn.Module drop-in + torch.optim.SGD (tool/train.py:269-276 unchanged)"),
@@ -479,12 +488,12 @@ def main():
                                 "every kernel on ONE stream (in_step: the same family over %d more steps in the two-stream "
                                 "configuration of the timed region; the timed region itself carries no events)"
                                 % (ISO_STEPS, ISO_STEPS))
-            _attach_pmc(roof, world)
+            _attach_pmc(roof, args, B)
             out["roofline"] = roof
             out["kernel_families"] = leg["kernel_families"]
             out["kernel_families_in_step"] = leg["kernel_families_in_step"]
             if exact is not None and isinstance(exact.get("roofline"), dict):
-                _attach_pmc(exact["roofline"], world)
+                _attach_pmc(exact["roofline"], args, B)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.layers, args.classes, args.size, arch=args.arch)
         print(json.dumps(out))
@@ -493,20 +502,32 @@ def main():
         dist.destroy_process_group()
 
 
-def _attach_pmc(roof, world):
+def workload_name(args, B):
+    return ("PS%sNet%d %s %dx%d, %d classes, global batch %d (per-GPU %d), train step fwd+loss+bwd+SGD, SyncBN, random-init weights"
+            % ("P" if args.arch == "psp" else "A", args.layers, shape_name(args.size, args.classes), args.size, args.size,
+               args.classes, args.global_batch, B))
+
+
+def _attach_pmc(roof, args, B):
     """HBM traffic / matrix-pipe busy fraction of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot
-    run inside this process; the file records the exact commands and corrections)."""
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
+    run inside this process; the file records the exact commands and corrections).  Only from a file collected on THIS network,
+    size, class count and PER-GPU batch on gfx950; otherwise `traffic` stays null."""
+    import re
+    want = re.sub(r"global batch \d+ ", "", workload_name(args, B))      # the per-GPU batch decides a launch's bytes
+    for name in PMC_FILES:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if re.sub(r"global batch \d+ ", "", pmc.get("workload", "")) != want or pmc.get("arch", "gfx950") != "gfx950":
+            continue
         key = roof["kernel"].split("+")[0].split("(")[0].replace(" ", "")
-        for k, v in pmc.items():
+        for k, v in pmc["kernels"].items():
             if k.replace(" ", "") == key:
                 roof["traffic"] = v["hbm_bytes_per_launch"]
-                roof["traffic_unit"] = ("bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/" + PMC_FILE
-                                        + (")" if world == 1 else "; collected at n_gpus=1, per-GPU batch 16)"))
+                roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/%s: %s)" % (name, pmc["workload"])
                 roof["mfma_busy_frac_pmc"] = v.get("mfma_busy_frac")
-    except Exception:
-        pass
+        return
 
 
 if __name__ == "__main__":

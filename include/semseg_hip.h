@@ -178,8 +178,11 @@ int semseg_wino_filter_grad(const float* dU, float* dw_oihw, int Co, int Ci, int
 /* Stem conv 3->64, 3x3 stride 2 pad 1, reading the caller's NCHW input (model/resnet.py:108). */
 int semseg_stem_conv_fwd(const float* x_nchw, const float* w_oihw, float* y_nhwc, int N, int H,
                          int W, int Co, hipStream_t stream);
+/* weight gradient: per-workgroup partial slabs in `scratch` (>= semseg_stem_wgrad_scratch_floats floats) + one fold launch; no atomics:
+ * the result does not depend on the arrival order. */
+size_t semseg_stem_wgrad_scratch_floats(int N, int H, int W);
 int semseg_stem_conv_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, int N, int H,
-                           int W, int Co, int accumulate, hipStream_t stream);
+                           int W, int Co, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
 
 /* ---- nn.BatchNorm2d / nn.SyncBatchNorm (+ReLU, +residual, +Dropout2d) — model/resnet.py:64-69,
  * 88-92,109-113,136; model/pspnet.py:16-17,66-68,74-76; tool/train.py:142.
@@ -207,6 +210,23 @@ int semseg_bn_apply(const float* y, int ldy, const float* scale, const float* sh
                     const float* y2, int ldy2, const float* scale2, const float* shift2,
                     const float* res, int ldres, const float* dropmask, float* out, int ldout,
                     int M, int C, int HW, int relu, unsigned* relu_bits, int ldbits, hipStream_t stream);
+/* semseg_bn_finalize + semseg_bn_apply of ONE training-mode BatchNorm in one launch (round 6; what the engine runs where the
+ * producers used nslot <= 2, i.e. at a small per-GPU batch, where a BatchNorm layer is otherwise four latency-bound launches):
+ * every thread derives scale / shift of its 4 channels from stats ([nslot][2*C], after the SyncBN all-reduce when there is one)
+ * with the expressions of semseg_bn_finalize — bit-identical values — and one row group also writes mean / invstd (read by
+ * the backward kernels), the running statistics (NULL: not tracked) and *num_batches_tracked += 1. */
+int semseg_bn_apply_train(const float* y, int ldy, const double* stats, int nslot, double count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                          float momentum, float eps, float* mean, float* invstd, const float* res, int ldres,
+                          const float* dropmask, float* out, int ldout, int M, int C, int HW, int relu, unsigned* relu_bits,
+                          int ldbits, hipStream_t stream);
+/* semseg_bn_param_grads + semseg_bn_bwd_apply in one launch: sums is [nslot][2*C]; dgamma = param_scale * sum g*xhat,
+ * dbeta = param_scale * sum g (dgamma NULL: not written).  Single process: the local sums, param_scale 1.  Under SyncBN the
+ * call follows the all-reduce, sums are GLOBAL and param_scale = 1 / world: every rank then holds global / world, which is
+ * what the gradient all-reduce (sum) followed by the 1 / world scale makes of torch's per-rank local gradients as well. */
+int semseg_bn_bwd_apply_train(const float* g, int ldg, const float* y, int ldy, const float* mean, const float* invstd,
+                              const float* gamma, const double* sums, int nslot, double count, double param_scale,
+                              float* dgamma, float* dbeta, float* dy, int lddy, int M, int C, hipStream_t stream);
 /* g = dout (*dropmask) (*[out>0]); sums += {sum g, sum g*xhat}; g optionally written. */
 int semseg_bn_bwd_reduce(const float* dout, int lddout, const float* out, int ldout,
                          const float* dropmask, int HW, const float* y, int ldy, const float* mean,

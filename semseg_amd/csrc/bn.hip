@@ -371,6 +371,165 @@ __global__ void bn_param_grads_kernel(double* sums, int nslot, float* dgamma, fl
   dbeta[c] = accumulate ? dbeta[c] + db : db;
 }
 
+// ---- Small-grid forms (round 6): the statistics -> scale / shift step (bn_finalize) folded into the apply kernel and the
+// parameter gradients (bn_param_grads) into the backward apply kernel.  At a small per-GPU batch (M = 7 200 pixels per image
+// pair: what each of 8 GPUs runs) a BatchNorm layer is four launches of 5-12 us, all latency; these forms make it two.  Every
+// thread keeps 4 channels over a strided row walk and derives scale / shift (sums of g) for them from the [nslot][2C] fp64
+// vector itself — the SAME expressions in the same order as bn_finalize_kernel / bn_bwd_apply_kernel, so the values are
+// bit-identical to the separate kernels' — and the threads of the first row group write what only one thread may write:
+// mean / invstd (backward reads them), the running statistics, num_batches_tracked; dgamma / dbeta.  The launcher bounds the
+// grid (<= 512 workgroups) so that the per-thread derivation is amortised over >= 4 rows wherever the tensor has them; the
+// engine selects these forms only where nslot <= 2 (few producer workgroups per address), see Engine.nslot_for.
+struct ApplyTrainArgs {
+  const float* y; const double* stats; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; long long* nbt;
+  float* mean; float* invstd;
+  const float* res; const float* dropmask;
+  float* out;
+  unsigned* bits;
+  double count;
+  float momentum, eps;
+  int nslot, ldy, ldres, ldout, ldbits, M, C, HW, relu, tpr, rpb;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_train_kernel(const ApplyTrainArgs p) {
+  const int CV = p.C >> 2;
+  const int tc = threadIdx.x % p.tpr, tr = threadIdx.x / p.tpr;
+  const int c4 = blockIdx.x * p.tpr + tc;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && p.nbt) *p.nbt += 1;
+  if (c4 >= CV) return;
+  const int c = c4 * 4;
+  f32x4 sc, sh;
+  const bool writer = blockIdx.y == 0 && tr == 0;
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < p.nslot; ++s) {
+      s1 += p.stats[(size_t)s * 2 * p.C + c + k];
+      s2 += p.stats[(size_t)s * 2 * p.C + p.C + c + k];
+    }
+    const double mu = s1 / p.count;
+    double var = s2 / p.count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float m = (float)mu;
+    sc[k] = ga[k] * is;
+    sh[k] = be[k] - m * sc[k];
+    if (writer) {
+      p.mean[c + k] = m;
+      p.invstd[c + k] = is;
+      if (p.running_mean) {
+        const double unb = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+        p.running_mean[c + k] = (1.f - p.momentum) * p.running_mean[c + k] + p.momentum * m;
+        p.running_var[c + k] = (1.f - p.momentum) * p.running_var[c + k] + p.momentum * (float)unb;
+      }
+    }
+  }
+  constexpr int U = 4;
+  const int step = gridDim.y * p.rpb;
+  const int sub = c4 & 7;
+  for (int mb = blockIdx.y * p.rpb + tr; mb < p.M; mb += U * step) {
+    f32x4 v[U], rr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = mb + u * step < p.M ? mb + u * step : mb;
+      v[u] = *reinterpret_cast<const f32x4*>(p.y + (size_t)m * p.ldy + c);
+      if (p.res) rr[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + c);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = mb + u * step;
+      // (the 8 lanes of a 32-channel word share tr and therefore m: the group is uniformly in or out of range)
+      if (m < p.M) {
+        f32x4 o = v[u] * sc + sh;
+        if (p.res) o += rr[u];
+        if (p.bits) {
+          unsigned w = ((o[0] > 0.f ? 1u : 0u) | (o[1] > 0.f ? 2u : 0u) | (o[2] > 0.f ? 4u : 0u) | (o[3] > 0.f ? 8u : 0u))
+                       << (4 * sub);
+          w |= __shfl_xor(w, 1);
+          w |= __shfl_xor(w, 2);
+          w |= __shfl_xor(w, 4);
+          if (sub == 0) p.bits[(size_t)m * p.ldbits + (c >> 5)] = w;
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
+        }
+        if (p.dropmask) o *= *reinterpret_cast<const f32x4*>(p.dropmask + (size_t)(m / p.HW) * p.C + c);
+        *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.ldout + c) = o;
+      }
+    }
+  }
+}
+
+struct BwdApplyTrainArgs {
+  const float* g; const float* y; const float* mean; const float* invstd; const float* gamma;
+  const double* sums;
+  float* dy; float* dgamma; float* dbeta;
+  double inv_count, pscale;
+  int nslot, ldg, ldy, lddy, M, C, tpr, rpb;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_train_kernel(const BwdApplyTrainArgs p) {
+  const int CV = p.C >> 2;
+  const int tc = threadIdx.x % p.tpr, tr = threadIdx.x / p.tpr;
+  const int c4 = blockIdx.x * p.tpr + tc;
+  if (c4 >= CV) return;
+  const int c = c4 * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c);
+  const f32x4 is = *reinterpret_cast<const f32x4*>(p.invstd + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+  const bool writer = blockIdx.y == 0 && tr == 0 && p.dgamma;
+  f32x4 A, mg, AX;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double s1 = p.sums[c + k], s2 = p.sums[p.C + c + k];
+    for (int s = 1; s < p.nslot; ++s) {
+      s1 += p.sums[(size_t)s * 2 * p.C + c + k];
+      s2 += p.sums[(size_t)s * 2 * p.C + p.C + c + k];
+    }
+    if (writer) {
+      p.dgamma[c + k] = (float)(s2 * p.pscale);
+      p.dbeta[c + k] = (float)(s1 * p.pscale);
+    }
+    mg[k] = (float)(s1 * p.inv_count);
+    A[k] = ga[k] * is[k];
+    AX[k] = A[k] * (float)(s2 * p.inv_count);
+  }
+  constexpr int U = 4;
+  const int step = gridDim.y * p.rpb;
+  for (int mb = blockIdx.y * p.rpb + tr; mb < p.M; mb += U * step) {
+    f32x4 g[U], yy[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = mb + u * step < p.M ? mb + u * step : mb;
+      g[u] = *reinterpret_cast<const f32x4*>(p.g + (size_t)m * p.ldg + c);
+      yy[u] = *reinterpret_cast<const f32x4*>(p.y + (size_t)m * p.ldy + c);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = mb + u * step;
+      if (m < p.M) {
+        const f32x4 xh = (yy[u] - mu) * is;
+        const f32x4 r = A * (g[u] - mg) - AX * xh;
+        *reinterpret_cast<f32x4*>(p.dy + (size_t)m * p.lddy + c) = r;
+      }
+    }
+  }
+}
+
+// grid of the two kernels above: gx column groups x gy row groups, <= 512 workgroups, >= 4 rows per thread where M allows
+inline int train_rows_grid(int M, int rpb, int gx) {
+  int gy = (M + rpb * 4 - 1) / (rpb * 4);
+  int cap = 512 / gx;
+  if (cap < 1) cap = 1;
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  return gy;
+}
+
 inline int flat_grid(size_t total) {
   size_t g = (total + 255) / 256;
   if (g > 4096) g = 4096;
@@ -430,6 +589,38 @@ int semseg_bn_apply(const float* y, int ldy, const float* scale, const float* sh
   ApplyArgs a{y, scale, shift, y2, scale2, shift2, res, dropmask, out,
               ldy, ldy2, ldres, ldout, M, C, HW, relu, relu_bits, ldbits};
   bn_apply_kernel<<<flat_grid((size_t)M * (C >> 2)), 256, 0, stream>>>(a);
+  return semseg_launch_status();
+}
+
+int semseg_bn_apply_train(const float* y, int ldy, const double* stats, int nslot, double count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                          float momentum, float eps, float* mean, float* invstd, const float* res, int ldres,
+                          const float* dropmask, float* out, int ldout, int M, int C, int HW, int relu, unsigned* relu_bits,
+                          int ldbits, hipStream_t stream) {
+  if (!y || !stats || !gamma || !beta || !mean || !invstd || !out || (C & 3) || (ldy & 3) || (ldout & 3) || count <= 0 ||
+      nslot < 1 || M <= 0)
+    return SEMSEG_EINVAL;
+  if (res && (ldres & 3)) return SEMSEG_EINVAL;
+  if (relu_bits && ((C & 31) || ldbits * 32 < C)) return SEMSEG_EINVAL;
+  const Tiling t = make_tiling(C >> 2);
+  ApplyTrainArgs a{y, stats, gamma, beta, running_mean, running_var, num_batches_tracked, mean, invstd, res, dropmask, out,
+                   relu_bits, count, momentum, eps, nslot, ldy, ldres, ldout, ldbits, M, C, HW, relu, t.tpr, t.rpb};
+  dim3 grid(t.gx, train_rows_grid(M, t.rpb, t.gx));
+  bn_apply_train_kernel<<<grid, 256, 0, stream>>>(a);
+  return semseg_launch_status();
+}
+
+int semseg_bn_bwd_apply_train(const float* g, int ldg, const float* y, int ldy, const float* mean, const float* invstd,
+                              const float* gamma, const double* sums, int nslot, double count, double param_scale,
+                              float* dgamma, float* dbeta, float* dy, int lddy, int M, int C, hipStream_t stream) {
+  if (!g || !y || !mean || !invstd || !gamma || !sums || !dy || (C & 3) || (ldg & 3) || (ldy & 3) || (lddy & 3) ||
+      count <= 0 || nslot < 1 || M <= 0 || (dgamma && !dbeta))
+    return SEMSEG_EINVAL;
+  const Tiling t = make_tiling(C >> 2);
+  BwdApplyTrainArgs a{g, y, mean, invstd, gamma, sums, dy, dgamma, dbeta, 1.0 / count, param_scale, nslot, ldg, ldy, lddy,
+                      M, C, t.tpr, t.rpb};
+  dim3 grid(t.gx, train_rows_grid(M, t.rpb, t.gx));
+  bn_bwd_apply_train_kernel<<<grid, 256, 0, stream>>>(a);
   return semseg_launch_status();
 }
 

@@ -54,11 +54,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 }
 
 // dW[co][ci][r][s] = sum over pixels dy[m][co] * x[n][ci][2oh+r-1][2ow+s-1].
-// Thread = (co, pixel sub-stream); 27 accumulators per thread; fp32 atomics merge blocks.
+// Thread = (co, pixel sub-stream); 27 accumulators per thread; a workgroup folds its four sub-streams through LDS and stores ONE
+// partial [27][CO] slab; stem_wgrad_fold_kernel sums the slabs.  (Rounds 1-5 merged the workgroups with fp32 atomics: 1024
+// workgroups x 1728 atomics on the same 54 cache lines were a fixed ~400 us tail — 454 us at per-GPU batch 2, 834 us at batch 16,
+// profiles/r06_bs2_serial_family_stats.csv — and made the result depend on the arrival order.)
 template <int CO>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ dy,
-                                                         float* __restrict__ dw, int N, int H,
+                                                         float* __restrict__ partial, int N, int H,
                                                          int W, int Ho, int Wo) {
   constexpr int PARTS = 256 / CO;
   const int co = threadIdx.x % CO;
@@ -88,12 +91,30 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
   for (int k = 0; k < 27; ++k) red[k * 256 + threadIdx.x] = acc[k];
   __syncthreads();
+  float* slab = partial + (size_t)blockIdx.x * (27 * CO);
   for (int i = threadIdx.x; i < 27 * CO; i += 256) {
     const int c = i % CO, k = i / CO;
     float v = 0.f;
     for (int pp = 0; pp < PARTS; ++pp) v += red[k * 256 + pp * CO + c];
-    atomicAdd(&dw[c * 27 + k], v);
+    slab[c * 27 + k] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_fold_kernel(const float* __restrict__ partial, int slabs, int n,
+                                                              float* __restrict__ dw, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int s = 0;
+  for (; s + 3 < slabs; s += 4) {
+    v0 += partial[(size_t)s * n + i];
+    v1 += partial[(size_t)(s + 1) * n + i];
+    v2 += partial[(size_t)(s + 2) * n + i];
+    v3 += partial[(size_t)(s + 3) * n + i];
+  }
+  for (; s < slabs; ++s) v0 += partial[(size_t)s * n + i];
+  const float v = (v0 + v1) + (v2 + v3);
+  dw[i] = accumulate ? dw[i] + v : v;
 }
 
 }  // namespace
@@ -111,16 +132,24 @@ int semseg_stem_conv_fwd(const float* x_nchw, const float* w_oihw, float* y_nhwc
   return semseg_launch_status();
 }
 
-// dw_oihw must be zero-filled by the caller when accumulate == 0 semantics are wanted
-// (the kernel always adds); the wrapper does the memset itself.
-int semseg_stem_conv_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, int N, int H,
-                           int W, int Co, int accumulate, hipStream_t stream) {
-  if (!x_nchw || !dy_nhwc || !dw_oihw || Co != 64) return SEMSEG_EINVAL;
+// scratch: >= semseg_stem_wgrad_scratch_floats(N, H, W) floats on the launch stream's arena (per-workgroup partial slabs).
+size_t semseg_stem_wgrad_scratch_floats(int N, int H, int W) {
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  if (!accumulate) {
-    if (hipMemsetAsync(dw_oihw, 0, sizeof(float) * Co * 27, stream) != hipSuccess) return SEMSEG_ELAUNCH;
-  }
-  stem_wgrad_kernel<64><<<1024, 256, 0, stream>>>(x_nchw, dy_nhwc, dw_oihw, N, H, W, Ho, Wo);
+  long long g = ((long long)N * Ho * Wo + 1023) / 1024;
+  if (g < 32) g = 32;
+  if (g > 512) g = 512;
+  return (size_t)g * 27 * 64;
+}
+
+int semseg_stem_conv_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, int N, int H,
+                           int W, int Co, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+  if (!x_nchw || !dy_nhwc || !dw_oihw || Co != 64 || !scratch) return SEMSEG_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t need = semseg_stem_wgrad_scratch_floats(N, H, W);
+  if (scratch_floats < need) return SEMSEG_EINVAL;
+  const int grid = (int)(need / (27 * 64));
+  stem_wgrad_kernel<64><<<grid, 256, 0, stream>>>(x_nchw, dy_nhwc, scratch, N, H, W, Ho, Wo);
+  stem_wgrad_fold_kernel<<<(27 * 64 + 255) / 256, 256, 0, stream>>>(scratch, grid, 27 * 64, dw_oihw, accumulate);
   return semseg_launch_status();
 }
 

@@ -138,6 +138,18 @@ RELU_BITS = os.environ.get("SEMSEG_RELU_BITS", "1") != "0"
 XCHG_HOST_OP = os.environ.get("SEMSEG_XCHG_HOST_OP", "0") == "1"
 WGRAD_EXACT_1X1_ONLY = os.environ.get("SEMSEG_WGRAD_EXACT_1X1_ONLY", "0") == "1"     # measurement: the long-reduction rule for 1x1 convs only
 WGRAD_BF16X3_MAX_M = int(os.environ.get("SEMSEG_WGRAD_BF16X3_MAX_M", "131072"))   # longer weight-gradient reductions: exact fp32 products
+# Round 6, small per-GPU batch: a BatchNorm layer whose tensor has few pixels gets few producer workgroups per statistics
+# address, so its [2C] fp64 vectors need 1-2 slot replicas instead of NSLOT — and with so few replicas the apply kernels can
+# derive scale / shift (and the parameter gradients) themselves: semseg_bn_apply_train / semseg_bn_bwd_apply_train, two
+# launches per layer and pass instead of four (SEMSEG_BN_FUSE_SMALL=0: the four-launch form everywhere; A/B).
+BN_FUSE_SMALL = os.environ.get("SEMSEG_BN_FUSE_SMALL", "1") != "0"
+BN_SMALL_M = (16384, 32768)       # pixels: <= [0] one replica, <= [1] two, above NSLOT (and the separate finalize kernels)
+
+
+def nslot_for(M):
+    if not BN_FUSE_SMALL:
+        return ops.NSLOT
+    return 1 if M <= BN_SMALL_M[0] else (2 if M <= BN_SMALL_M[1] else ops.NSLOT)
 
 
 def set_arith(name):
@@ -236,6 +248,8 @@ class BNL:
         self.ggrad = None
         self.bgrad = None
         self.eval_epoch = -1
+        self.ns = ops.NSLOT     # slot replicas of stats / sums the producers of THIS layer use (nslot_for(pixels), set by its producer)
+        self.fin = None         # (stats vector, replicas, count, tracked): bn_prepare_group left the finalize step to bn_act's apply launch
 
 
 # HIP streams (and the split-K scratch arenas that go with them) are shared by every engine of a process, per device.
@@ -548,6 +562,8 @@ class Engine:
                 return out
             assert fold is None
             V = self.buf((16 * T * cl.Ci,), tag="winoV")      # kept: the weight gradient contracts it with dy
+            if stats is not None:
+                stats.ns = nslot_for(out.M)
             self._wino_rows(x.data, x.ld, cl.Ci, cl.wino.U_fwd, cl.wino.Co_pad, out.data, out.ld, cl.Co, x.N, x.H, x.W,
                             cl.dil, T, V, stats=stats, arith=cl.arith)
             if x.fuse_ok:
@@ -568,9 +584,12 @@ class Engine:
                          bias=sh, scale=sc, relu=relu, add=None if res is None else res.data,
                          ldadd=0 if res is None else res.ld, scratch=self.scratch(), arith=ar)
         else:
+            if stats is not None:
+                stats.ns = nslot_for(out.M)
             ops.conv_fwd(x.data, x.ld, cl.pk, out.data, out.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
-                         bias=m.bias.detach() if (bias and m.bias is not None) else None, stats=stats,
-                         nslot=ops.NSLOT, scratch=self.scratch(), arith=ar)
+                         bias=m.bias.detach() if (bias and m.bias is not None) else None,
+                         stats=None if stats is None else stats.stats,
+                         nslot=1 if stats is None else stats.ns, scratch=self.scratch(), arith=ar)
         self._t1(ev)
         if self.training:
             if x.fuse_ok:
@@ -656,7 +675,7 @@ class Engine:
                 ops.conv_dgrad_bnreduce(dy, y.ld, cl.pk, gx, x.ld, x.N, x.H, x.W, cl.stride, cl.pad, cl.dil,
                                         x.data if bs["relu"] else None, x.ld,
                                         [(yk.data, yk.ld, blk.mean, blk.invstd, blk.sums) for yk, blk in bs["bns"]],
-                                        ops.NSLOT, add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch(),
+                                        bs["bns"][0][1].ns, add=gx if x.ginit else None, ldadd=x.ld, scratch=self.scratch(),
                                         arith=ar, relu_bits=x.bits if bs["relu"] else None)
                 x.bn_reduced = True
             else:
@@ -697,13 +716,14 @@ class Engine:
         self._t1(ev)
         ev = self._t0(WINO_HBM, -4.0 * (16 * T * Nout + px * Nout * (1 + (add is not None) + ((1 + (1.0 if bnr[7] is None else 1.0 / 32)) if bnr else 0))))
         if bnr is not None:
-            act, ldact, ybn, ldybn, mean, invstd, sums, bits = bnr
+            act, ldact, ybn, ldybn, mean, invstd, sums, bits, ns = bnr
             ops.wino_output_transform_bnreduce(Mb, Nout, dst, ldd, N, H, W, Nout, d, act, ldact, ybn, ldybn, mean,
-                                               invstd, sums, ops.NSLOT, add=add, ldadd=ldadd, relu_bits=bits)
+                                               invstd, sums, ns, add=add, ldadd=ldadd, relu_bits=bits)
         else:
             sc, sh, relu = fold if fold is not None else (None, None, False)
-            ops.wino_output_transform(Mb, Nout, dst, ldd, N, H, W, Nout, d, add=add, ldadd=ldadd, stats=stats,
-                                      nslot=ops.NSLOT, scale=sc, shift=sh, relu=relu)
+            ops.wino_output_transform(Mb, Nout, dst, ldd, N, H, W, Nout, d, add=add, ldadd=ldadd,
+                                      stats=None if stats is None else stats.stats, nslot=1 if stats is None else stats.ns,
+                                      scale=sc, shift=sh, relu=relu)
         self._t1(ev)
 
     def _conv_bwd_wino(self, x, y, cl, m, V, T):
@@ -750,7 +770,7 @@ class Engine:
                     and bs["bns"][0][0].ld % 4 == 0):
                 yk, blk = bs["bns"][0]
                 bnr = (x.data if bs["relu"] else None, x.ld, yk.data, yk.ld, blk.mean, blk.invstd, blk.sums,
-                       x.bits if bs["relu"] else None)
+                       x.bits if bs["relu"] else None, blk.ns)
             self._wino_rows(dy, y.ld, cl.wino.Kc, cl.wino.U_dgrad, cl.wino.Ci_pad, gx, x.ld, cl.Ci, N, H, W, d, T,
                             self._wino_scratch("Vdy", 16 * T * cl.wino.Kc), add=gx if x.ginit else None, ldadd=x.ld,
                             bnr=bnr, arith=cl.arith)
@@ -879,28 +899,35 @@ class Engine:
         """stats -> scale/shift (train: batch statistics, SyncBN all-reduce; eval: running stats)."""
         return self.bn_prepare_group([(bm, count)])[0]
 
-    def bn_prepare_group(self, items):
+    def bn_prepare_group(self, items, fuse_ok=True):
         """items: [(BatchNorm module, values per channel on this rank)] of layers whose statistics are all complete.
         Under SyncBN the group's [sum, sum of squares] vectors are combined into one staging vector and all-reduced
-        ONCE.  Returns the global count per layer (0 for layers normalising with running statistics)."""
+        ONCE.  Returns the global count per layer (0 for layers normalising with running statistics).
+        fuse_ok: the caller's apply launch handles ONE BatchNorm, so for layers with <= 2 slot replicas the finalize step is
+        left to it (BNL.fin -> semseg_bn_apply_train) instead of being launched here."""
         out = []
         train = [(bm, c) for bm, c in items if self.training and bm.training]
         if train and self._syncing():
             bls = [self.bns[bm] for bm, _ in train]
             if len(bls) == 1:
-                views = [bls[0].stats[:2 * bls[0].C]]
-                self._all_reduce(views[0], src=bls[0].stats, nslot=ops.NSLOT)
+                bl = bls[0]
+                views = [bl.stats[:2 * bl.C]]
+                if bl.ns == 1:
+                    self._all_reduce(views[0])          # one replica: the vector is what SyncBN all-reduces as it lies
+                else:
+                    self._all_reduce(views[0], src=bl.stats, nslot=bl.ns)
             else:
                 g = self._group(bls)
                 views = [g.view(bl) for bl in bls]
                 for bl, v in zip(bls, views):
-                    ops.bn_combine(bl.stats, ops.NSLOT, bl.C, dst=v)
+                    ops.bn_combine(bl.stats, bl.ns, bl.C, dst=v)
                 self._all_reduce(g.buf)
             src = {id(bm): (v, 1) for (bm, _), v in zip(train, views)}
         else:
-            src = {id(bm): (self.bns[bm].stats, ops.NSLOT) for bm, _ in train}
+            src = {id(bm): (self.bns[bm].stats, self.bns[bm].ns) for bm, _ in train}
         for bm, count in items:
             bl = self.bns[bm]
+            bl.fin = None
             if id(bm) in src:
                 st, ns = src[id(bm)]
                 cnt = count * self.world if self._syncing() else count
@@ -908,9 +935,14 @@ class Engine:
                     raise ValueError("Expected more than 1 value per channel when training, got input "
                                      "size [%d values per channel]" % cnt)
                 track = bm.track_running_stats and bm.running_mean is not None
-                # (folding this step into the apply kernel — every thread deriving scale / shift of its 4 channels from the
-                # [nslot][2C] sums — was built and measured in round 4: the ~1 M threads of an apply launch re-read 512 B of
-                # sums each, 42 us instead of 5 us per launch at per-GPU batch 2, +8 ms per step at batch 16)
+                if BN_FUSE_SMALL and fuse_ok and ns <= 2 and bl.C % 4 == 0:
+                    bl.fin = (st, ns, cnt, track)
+                    out.append(cnt)
+                    continue
+                # (folding this step into the apply kernel for EVERY layer — every thread deriving scale / shift of its 4
+                # channels from the [nslot][2C] sums — was built and measured in round 4: the ~1 M threads of an apply launch
+                # re-read 512 B of sums each, +8 ms per step at batch 16; DESIGN.md 8.5.  Round 6 does it where there are <= 2
+                # replicas, with a bounded grid: bl.fin above)
                 ops.bn_finalize(st, cnt, bm.weight.detach(), bm.bias.detach(),
                                 bm.running_mean if track else None, bm.running_var if track else None,
                                 bm.num_batches_tracked if track else None, bl.momentum, bl.eps, bl.mean,
@@ -932,7 +964,7 @@ class Engine:
         if y2 is not None:
             assert prepared is None
             bl2 = self.bns[bm2]
-            cnt = self.bn_prepare_group([(bm, y.M), (bm2, y2.M)])[0]
+            cnt = self.bn_prepare_group([(bm, y.M), (bm2, y2.M)], fuse_ok=False)[0]
         else:
             cnt = self.bn_prepare(bm, y.M) if prepared is None else prepared
         if out is None:
@@ -941,11 +973,21 @@ class Engine:
         # itself (1/32 of its bytes; the activation is the largest operand of a 1x1 data gradient's epilogue).
         if RELU_BITS and self.training and relu and dropmask is None and y.C % 32 == 0:
             out.bits = self.buf((y.M, y.C // 32), dtype=torch.int32, tag="relubits")
-        ops.bn_apply(y.data, y.ld, bl.scale, bl.shift, out.data, out.ld, y.M, y.C, y.H * y.W, relu,
-                     y2=None if y2 is None else y2.data, ldy2=0 if y2 is None else y2.ld,
-                     scale2=None if bl2 is None else bl2.scale, shift2=None if bl2 is None else bl2.shift,
-                     res=None if res is None else res.data, ldres=0 if res is None else res.ld,
-                     dropmask=dropmask, relu_bits=out.bits)
+        if bl.fin is not None:
+            assert y2 is None
+            st, ns, fcnt, track = bl.fin
+            bl.fin = None
+            ops.bn_apply_train(y.data, y.ld, st, ns, fcnt, bm.weight.detach(), bm.bias.detach(),
+                               bm.running_mean if track else None, bm.running_var if track else None,
+                               bm.num_batches_tracked if track else None, bl.momentum, bl.eps, bl.mean, bl.invstd,
+                               out.data, out.ld, y.M, y.C, y.H * y.W, relu, res=None if res is None else res.data,
+                               ldres=0 if res is None else res.ld, dropmask=dropmask, relu_bits=out.bits)
+        else:
+            ops.bn_apply(y.data, y.ld, bl.scale, bl.shift, out.data, out.ld, y.M, y.C, y.H * y.W, relu,
+                         y2=None if y2 is None else y2.data, ldy2=0 if y2 is None else y2.ld,
+                         scale2=None if bl2 is None else bl2.scale, shift2=None if bl2 is None else bl2.shift,
+                         res=None if res is None else res.data, ldres=0 if res is None else res.ld,
+                         dropmask=dropmask, relu_bits=out.bits)
         if self.training:
             if dropmask is None:
                 out.bnsrc = dict(bns=[(y, bl)] + ([(y2, bl2)] if y2 is not None else []), relu=relu)
@@ -980,10 +1022,10 @@ class Engine:
             else:
                 g, ldg = gy, y.ld
             ops.bn_bwd_reduce(dout, out.ld, out.data if relu else None, out.ld, dropmask, y.H * y.W, y.data,
-                              y.ld, bl.mean, bl.invstd, g, ldg, bl.sums, y.M, y.C, nslot=ops.NSLOT)
+                              y.ld, bl.mean, bl.invstd, g, ldg, bl.sums, y.M, y.C, nslot=bl.ns)
             if y2 is not None:
                 ops.bn_bwd_reduce(g, ldg, None, 0, None, y2.H * y2.W, y2.data, y2.ld, bl2.mean, bl2.invstd,
-                                  None, 0, bl2.sums, y2.M, y2.C, nslot=ops.NSLOT)
+                                  None, 0, bl2.sums, y2.M, y2.C, nslot=bl2.ns)
         members = ([(y2, bm2, bl2)] if y2 is not None else []) + [(y, bm, bl)]
         sync = self._syncing()
         if sync and group is None and len(members) > 1:
@@ -991,10 +1033,22 @@ class Engine:
             group.todo = 1
         if not sync:
             group = None
+        if BN_FUSE_SMALL and group is None and len(members) == 1 and bl.ns <= 2 and bl.C % 4 == 0:
+            # small tensor, one BatchNorm, no group: the parameter gradients ride in the backward apply launch (and the slot
+            # replicas are folded there).  Under SyncBN it follows the all-reduce: the sums are global and every rank writes
+            # global / world — what the gradient all-reduce + 1 / world makes of torch's per-rank local gradients too.
+            if sync:
+                self._all_reduce(bl.sums[:2 * bl.C], src=bl.sums if bl.ns > 1 else None, nslot=bl.ns)
+            ops.bn_bwd_apply_train(g, ldg, y.data, y.ld, bl.mean, bl.invstd, bm.weight.detach(), bl.sums,
+                                   1 if sync else bl.ns, cnt, 1.0 / self.world if sync else 1.0, bl.ggrad, bl.bgrad,
+                                   self.grad_of(y), y.ld, y.M, y.C)
+            y.ginit = True
+            self._ready([bm.weight, bm.bias])
+            return
         # parameter gradients come from the LOCAL sums (torch SyncBatchNorm semantics); the folded [2C] vector — what
         # the input gradient needs summed over all ranks — lands in slot 0 or in the group's staging piece
         for yy, bmm, bll in members:
-            ops.bn_param_grads(bll.sums, bll.ggrad, bll.bgrad, bll.C, nslot=ops.NSLOT,
+            ops.bn_param_grads(bll.sums, bll.ggrad, bll.bgrad, bll.C, nslot=bll.ns,
                                folded=None if group is None else group.view(bll))
 
         def finish():
@@ -1030,10 +1084,11 @@ class Engine:
         ops.stem_conv_fwd(x_nchw, w0, y0.data, N, H, W)
         bl = self.bns[l0[1]]
         if self.training and l0[1].training:
-            ops.channel_stats(y0.data, y0.ld, bl.stats, y0.M, 64, nslot=ops.NSLOT)
+            bl.ns = nslot_for(y0.M)
+            ops.channel_stats(y0.data, y0.ld, bl.stats, y0.M, 64, nslot=bl.ns)
         if self.training:
             def bwd():
-                ops.stem_conv_wgrad(x_nchw, y0.grad, self.grad_views[c0.weight], N, H, W)
+                ops.stem_conv_wgrad(x_nchw, y0.grad, self.grad_views[c0.weight], N, H, W, scratch=self.scratch())
                 self._ready([c0.weight])
             self.push("stem_wgrad", bwd, x=x_nchw, y=y0, m=c0)
         a = self.bn_act(y0, l0[1])
@@ -1053,7 +1108,8 @@ class Engine:
         return p
 
     def _st(self, bm):
-        return self.bns[bm].stats if (self.training and bm.training) else None
+        """The BNL whose statistics the producing conv accumulates (None: the layer normalises with running statistics)."""
+        return self.bns[bm] if (self.training and bm.training) else None
 
     def bottleneck(self, x, blk, out=None):
         a1 = self.conv_bn(x, blk.conv1, blk.bn1)

@@ -412,9 +412,11 @@ def stem_conv_fwd(x_nchw, w, y, N, H, W):
         "stem_conv_fwd")
 
 
-def stem_conv_wgrad(x_nchw, dy, dw, N, H, W, accumulate=False):
+def stem_conv_wgrad(x_nchw, dy, dw, N, H, W, accumulate=False, scratch=None):
+    if scratch is None:
+        scratch = torch.empty(int(lib.semseg_stem_wgrad_scratch_floats(N, H, W)), dtype=torch.float32, device=dy.device)
     _ck(lib.semseg_stem_conv_wgrad(_p(x_nchw), _p(dy), _p(dw), N, H, W, dw.shape[0], int(accumulate),
-                                   _stream()), "stem_conv_wgrad")
+                                   *_scr(scratch), _stream()), "stem_conv_wgrad")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -446,6 +448,22 @@ def bn_apply(y, ldy, scale, shift, out, ldout, M, C, HW, relu, y2=None, ldy2=0, 
     _ck(lib.semseg_bn_apply(_p(y), ldy, _p(scale), _p(shift), _p(y2), ldy2, _p(scale2), _p(shift2),
                             _p(res), ldres, _p(dropmask), _p(out), ldout, M, C, HW, int(relu),
                             _p(relu_bits), 0 if relu_bits is None else relu_bits.shape[-1], _stream()), "bn_apply")
+
+
+def bn_apply_train(y, ldy, stats, nslot, count, gamma, beta, rm, rv, nbt, momentum, eps, mean, invstd, out, ldout, M, C, HW,
+                   relu, res=None, ldres=0, dropmask=None, relu_bits=None):
+    """semseg_bn_finalize + semseg_bn_apply in one launch (small grids; include/semseg_hip.h)."""
+    _ck(lib.semseg_bn_apply_train(_p(y), ldy, _p(stats), nslot, float(count), _p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt),
+                                  momentum, eps, _p(mean), _p(invstd), _p(res), ldres, _p(dropmask), _p(out), ldout, M, C, HW,
+                                  int(relu), _p(relu_bits), 0 if relu_bits is None else relu_bits.shape[-1], _stream()),
+        "bn_apply_train")
+
+
+def bn_bwd_apply_train(g, ldg, y, ldy, mean, invstd, gamma, sums, nslot, count, param_scale, dgamma, dbeta, dy, lddy, M, C):
+    """semseg_bn_param_grads + semseg_bn_bwd_apply in one launch (small grids)."""
+    _ck(lib.semseg_bn_bwd_apply_train(_p(g), ldg, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(sums), nslot, float(count),
+                                      float(param_scale), _p(dgamma), _p(dbeta), _p(dy), lddy, M, C, _stream()),
+        "bn_bwd_apply_train")
 
 
 def bn_bwd_reduce(dout, lddout, out, ldout, dropmask, HW, y, ldy, mean, invstd, g, ldg, sums, M, C,

@@ -81,6 +81,10 @@ def _check_train(report, name, gold, pred, ml, al, grads, bufs):
             a, r = grads[k[5:]].cpu().numpy().astype(np.float64), gold[k].astype(np.float64)
             e_l2[k[5:]] = float(np.sqrt(((a - r) ** 2).sum() / max((r ** 2).sum(), 1e-300)))
     report("    relative L2 error of the stored gradients: %s" % {k: "%.1e" % v for k, v in e_l2.items()})
+    # bounds = 3 x the first measurement of each class over the three fixtures and both arithmetics (profiles/r06_parity_report.txt:
+    # heads <= 5.6e-5; layer0.1, the first BatchNorm below 100 layers of ReLU masks, 2.8e-2 - 7.7e-2 in EITHER arithmetic)
+    for k, v in e_l2.items():
+        assert v < (2e-4 if k.startswith(("cls.4.", "aux.4.")) else 2.5e-1), (k, v)
     for k, v in e_grad.items():
         # cls.4 / aux.4 (no ReLU mask between them and the loss): 5e-4 of their maximum.  Every other stored tensor sits below at
         # least one BatchNorm + ReLU, where two fp32 implementations differ element-wise through mask flips: layer0.1 (the FIRST
