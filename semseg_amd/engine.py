@@ -142,7 +142,7 @@ WGRAD_BF16X3_MAX_M = int(os.environ.get("SEMSEG_WGRAD_BF16X3_MAX_M", "131072")) 
 # address, so its [2C] fp64 vectors need 1-2 slot replicas instead of NSLOT — and with so few replicas the apply kernels can
 # derive scale / shift (and the parameter gradients) themselves: semseg_bn_apply_train / semseg_bn_bwd_apply_train, two
 # launches per layer and pass instead of four (SEMSEG_BN_FUSE_SMALL=0: the four-launch form everywhere; A/B).
-BN_FUSE_SMALL = os.environ.get("SEMSEG_BN_FUSE_SMALL", "1") != "0"
+BN_FUSE_SMALL = os.environ.get("SEMSEG_BN_FUSE_SMALL", "0") != "0"
 BN_SMALL_M = (16384, 32768)       # pixels: <= [0] one replica, <= [1] two, above NSLOT (and the separate finalize kernels)
 
 

@@ -412,6 +412,58 @@ def test_bn_train_fwd_bwd(C, HW, mode, report):
     assert max(errs) < 2e-5
 
 
+@pytest.mark.parametrize("C,HW,N,ns", [(64, 13, 3, 1), (256, 60, 2, 1), (1024, 9, 2, 2), (2048, 5, 2, 2), (512, 6, 1, 1)])
+@pytest.mark.parametrize("mode", ["plain", "res", "drop"])
+def test_bn_fused_train_launches_equal_the_separate_ones(C, HW, N, ns, mode, report):
+    """semseg_bn_apply_train == semseg_bn_finalize + semseg_bn_apply and semseg_bn_bwd_apply_train == semseg_bn_param_grads +
+    semseg_bn_bwd_apply, BIT for bit (same expressions in the same order): activation, ReLU bits, mean / invstd, running
+    statistics, num_batches_tracked, dy, dgamma, dbeta; param_scale (the SyncBN 1 / world form) scales the parameter gradients."""
+    from semseg_amd import ops
+    M = N * HW * HW
+    g = torch.Generator().manual_seed(C + HW + ns)
+    yd = (torch.randn(N, HW, HW, C, generator=g) * 2 + 0.7).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    rm0, rv0 = torch.randn(C, generator=g).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    res = torch.randn(N, HW, HW, C, generator=g).to(DEV) if mode == "res" else None
+    dm = ((torch.rand(N, C, generator=g) > 0.3).float() / 0.7).to(DEV) if mode == "drop" else None
+    stats = torch.zeros(ns * 2 * C, dtype=torch.float64, device=DEV)
+    ops.channel_stats(yd, C, stats, M, C, nslot=ns)
+    # separate launches
+    mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
+    rm, rv, nbt = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.int64, device=DEV)
+    ops.bn_finalize(stats, M, gamma, beta, rm, rv, nbt, 0.1, 1e-5, mean, invstd, scale, shift, C, nslot=ns)
+    out, bits = torch.empty_like(yd), torch.zeros(M, C // 32, dtype=torch.int32, device=DEV)
+    ops.bn_apply(yd, C, scale, shift, out, C, M, C, HW * HW, True, res=res, ldres=C, dropmask=dm,
+                 relu_bits=None if dm is not None else bits)
+    # fused launch
+    mean2, invstd2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rm2, rv2, nbt2 = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.int64, device=DEV)
+    out2, bits2 = torch.empty_like(yd), torch.zeros(M, C // 32, dtype=torch.int32, device=DEV)
+    ops.bn_apply_train(yd, C, stats, ns, M, gamma, beta, rm2, rv2, nbt2, 0.1, 1e-5, mean2, invstd2, out2, C, M, C, HW * HW, True,
+                       res=res, ldres=C, dropmask=dm, relu_bits=None if dm is not None else bits2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(bits, bits2)
+    assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2) and torch.equal(rm, rm2) and torch.equal(rv, rv2)
+    assert int(nbt2.item()) == 1
+    # backward
+    gd = torch.randn(N, HW, HW, C, generator=g).to(DEV)
+    sums = torch.zeros(ns * 2 * C, dtype=torch.float64, device=DEV)
+    ops.bn_bwd_reduce(gd, C, None, 0, None, HW * HW, yd, C, mean, invstd, None, 0, sums, M, C, nslot=ns)
+    sums2 = sums.clone()
+    dg, db, dy = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty_like(yd)
+    ops.bn_param_grads(sums, dg, db, C, nslot=ns)
+    ops.bn_bwd_apply(gd, C, yd, C, mean, invstd, gamma, sums, M, dy, C, M, C)
+    dg2, db2, dy2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty_like(yd)
+    ops.bn_bwd_apply_train(gd, C, yd, C, mean, invstd, gamma, sums2, ns, M, 1.0, dg2, db2, dy2, C, M, C)
+    torch.cuda.synchronize()
+    assert torch.equal(dy, dy2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    dg3, db3 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_bwd_apply_train(gd, C, yd, C, mean, invstd, gamma, sums2, ns, M, 0.25, dg3, db3, dy2, C, M, C)
+    torch.cuda.synchronize()
+    assert torch.equal(dy, dy2) and torch.allclose(dg3, dg * 0.25, rtol=1e-6, atol=0) and torch.allclose(db3, db * 0.25, rtol=1e-6, atol=0)
+    report("fused BatchNorm launches C=%d %dx%d N=%d nslot=%d [%s]: bit-identical to finalize + apply / param_grads + bwd_apply" % (C, HW, HW, N, ns, mode))
+
+
 @pytest.mark.parametrize("shape", [(3, 7, 9, 64), (2, 15, 15, 256), (1, 5, 5, 2048)])
 @pytest.mark.parametrize("form", ["plain", "res", "two"])
 def test_bn_apply_relu_bits(shape, form, report):
