@@ -76,17 +76,24 @@ int semseg_conv_pack_weights_multi(const SemsegPackDesc* descs_dev, const int* b
  * one fused BatchNorm layer and Co <= 1024 — and the 128 x 128 tile otherwise;
  * w_fwd must have Co_pad = roundup(Co, tile_n) rows.  Ci % 32 == 0.  scratch (optional) enables
  * split-K when the 128 x tile_n tile grid cannot fill the 256 CUs (small per-GPU batches). */
+/* tile_counters (optional; semseg_conv_fwd / _dgrad / _dgrad_bnreduce): SEMSEG_TILE_COUNTERS 32-bit words, ZERO before the first
+ * launch that is given them, owned by the stream the launches run on like scratch.  With them, tiles whose K range is split
+ * are reduced INSIDE the launch: each slice stores its accumulators into its own slab of scratch and draws a ticket from its
+ * tile's counter; the slice that draws the last ticket sums the slabs in slice order (the result does not depend on the arrival
+ * order) and runs the epilogue — instead of a second launch that re-reads every partial sum.  The launch leaves the counters
+ * zero.  NULL: the separate reduction launch of rounds 1-5. */
+#define SEMSEG_TILE_COUNTERS 4096
 int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int ldy, int N, int H,
                     int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
                     int dil, const float* bias, const float* scale, int relu, const float* add,
                     int ldadd, double* stats, int stats_nslot, int tile_n, int arith, float* scratch,
-                    size_t scratch_floats, hipStream_t stream);
+                    size_t scratch_floats, unsigned int* tile_counters, hipStream_t stream);
 /* dx[N*H*W][Ci] = conv_transpose(dy) (+add).  dy must be readable (zero padded) up to
  * roundup32(Co) channels; w_dgrad must have roundup(Ci, tile_n) rows. */
 int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
                       int pad, int dil, const float* add, int ldadd, int tile_n, int arith, float* scratch,
-                      size_t scratch_floats, hipStream_t stream);
+                      size_t scratch_floats, unsigned int* tile_counters, hipStream_t stream);
 /* Data gradient + the BatchNorm-backward reduction (torch batch_norm backward for model/resnet.py:76-92) of the
  * layer(s) that PRODUCED this conv's input, in one kernel: dx = g = (dgrad (+ add)) * (act > 0), and
  * sums{0,1}[nslot][2*Ci] += {sum g, sum g * (y - mean) * invstd} in fp64 (slot replicas as in semseg_channel_stats).
@@ -100,7 +107,8 @@ int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, 
                                const unsigned* relu_bits, int ldbits,
                                const float* y0, int ldy0, const float* mean0, const float* invstd0, double* sums0,
                                const float* y1, int ldy1, const float* mean1, const float* invstd1, double* sums1,
-                               int nslot, int arith, float* scratch, size_t scratch_floats, hipStream_t stream);
+                               int nslot, int arith, float* scratch, size_t scratch_floats, unsigned int* tile_counters,
+                               hipStream_t stream);
 /* dw_oihw[Co][Ci][R][S] (=|+=) sum over pixels; scratch holds the split-K partial slabs
  * (>= semseg_conv_wgrad_scratch_floats(...) floats; more slabs => more K parallelism AND shorter fp32
  * accumulation chains: with a single slab the whole pixel reduction is one chain and its rounding noise

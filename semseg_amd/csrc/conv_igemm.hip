@@ -12,6 +12,7 @@
 // Tile: 256 threads = 4 waves (2x2), block tile BM x BN x 32, each wave (BM/2)x(BN/2) as
 // 32x32 MFMA blocks; global->register prefetch of K-step t+1 overlaps the MFMAs of step t.
 // (The weight gradient lives in conv_wgrad.hip since round 4.)
+#include <cstdlib>
 #include "conv_common.h"
 #include "gemm_bf16split.h"
 
@@ -69,6 +70,12 @@ struct ConvArgs {
   const float* bnr_invstd[2];
   double* bnr_sums[2];            // [stats_nslot][2 * Nout]
   int gm;                         // tile rows per group of the workgroup order (decode_tile); <= 1: row-major
+  // In-kernel reduction of split tiles (round 6; cnt != nullptr): every (tile, ks) workgroup stores its accumulators as they lie
+  // in registers into slab [tile - full_tiles][ks] of `part` (write-through stores) and draws a ticket from cnt[tile - full_tiles];
+  // the workgroup that draws the last one sums the ksplit slabs in slice order and runs the UNSPLIT epilogue on the sum — no
+  // splitk_epilogue_kernel launch, no second trip of the partial sums through a [ksplit][M][N] array.  cnt is zero before the
+  // launch and left zero.
+  unsigned* cnt;
 };
 
 // Linear tile index -> (tile_m, tile_n).  Whole (unsplit) tiles are walked in groups of `gm` tile rows, row index
@@ -713,6 +720,64 @@ __global__ __launch_bounds__(BM * 2, CONV_OCC) void conv_igemm_kernel(const Conv
         for (int e = 0; e < 16; ++e) acc[i][j][e] += acc2[i][j][e];
   }
 
+  if (split && p.cnt) {
+    // hand-off of cdna_hip_programming.md guideline 16 (counter form): write-through (sc1) payload stores, every wave drains them,
+    // barrier, ONE lane draws a relaxed agent-scope ticket; the last arriver issues ONE agent-scope acquire and reads the slabs back
+    constexpr int QN = MREP * NREP * 4;                         // float4 per thread
+    const int st = tile - p.full_tiles;
+    const __amdgpu_buffer_rsrc_t rp_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.part, 0, 0x80000000, 0x00020000);
+    const unsigned slab_bytes = (unsigned)(BM * BN * 4);
+    const unsigned my = ((unsigned)st * (unsigned)p.ksplit + (unsigned)ks) * slab_bytes + (unsigned)tid * 16u;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const f32x4 v = {acc[i][j][4 * e4], acc[i][j][4 * e4 + 1], acc[i][j][4 * e4 + 2], acc[i][j][4 * e4 + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp_, my + (unsigned)(((i * NREP + j) * 4 + e4) * NT * 16), 0, 16);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      const unsigned tk = __hip_atomic_fetch_add(p.cnt + st, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = tk == (unsigned)p.ksplit - 1u;
+      if (last) {
+        __hip_atomic_store(p.cnt + st, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    const int last = *flag;
+    __syncthreads();                 // the epilogue reuses this LDS
+    if (!last) return;
+    // slice order, every slab read back (this workgroup's own included: the sum does not depend on who arrives last)
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const unsigned base0 = (unsigned)st * (unsigned)p.ksplit * slab_bytes + (unsigned)tid * 16u;
+    for (int k = 0; k < p.ksplit; ++k) {
+      f32x4 t[QN];
+#pragma unroll
+      for (int q = 0; q < QN; ++q)
+        t[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp_, base0 + (unsigned)k * slab_bytes + (unsigned)(q * NT * 16), 0, 16));
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[i][j][4 * e4 + c] += t[(i * NREP + j) * 4 + e4][c];
+    }
+    split = false;
+    ks = 0;
+  }
   conv_epilogue<BM, BN, !TR, TR>(p, acc, smem, split, ks, m0, n0, tile_m, reinterpret_cast<double*>(smem + RED2_OFF), p.y, p.add);
 }
 
@@ -1018,7 +1083,7 @@ static inline bool tile_code_ok(int t) { return t == 64 || t == 128 || t == 1064
 // arith (include/semseg_hip.h): SEMSEG_ARITH_BF16X3 selects the SP = 3 instances of the 1x1 / 3x3 buffer-load kernels
 // (products from three-way split bf16 pieces); the generic tap walk (RS_T = 0) has no split form and stays exact fp32.
 static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, int arith, float* scratch,
-                       size_t scratch_floats, hipStream_t stream) {
+                       size_t scratch_floats, unsigned* tile_counters, hipStream_t stream) {
   const bool sp3 = arith == SEMSEG_ARITH_BF16X3;
   const int BMr = tile_code >= 1000 ? 64 : 128;
   const int BN = tile_code % 1000;
@@ -1070,6 +1135,15 @@ static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, int ar
   p.ksplit = ksplit;
   p.full_tiles = ksplit > 1 ? full_tiles : tiles;
   p.part = scratch;
+  // In-kernel reduction of the split tiles (ConvArgs::cnt) when the caller gave tile counters: the last slice of a tile to finish
+  // sums the others' register-layout slabs — a serial read of ksplit x 32-64 KB by one workgroup, against a separate launch that
+  // re-reads every partial sum from a [ksplit][M][N] array: taken up to FUSED_SPLIT_MAX slices per tile (SEMSEG_FUSED_SPLIT_MAX).
+  static const int fused_max = [] { const char* e = getenv("SEMSEG_FUSED_SPLIT_MAX"); return e ? atoi(e) : 16; }();
+  p.cnt = nullptr;
+  if (ksplit > 1 && tile_counters && ksplit <= fused_max && (tiles - p.full_tiles) <= SEMSEG_TILE_COUNTERS &&
+      (size_t)(tiles - p.full_tiles) * ksplit * BMr * BN <= scratch_floats &&
+      (size_t)(tiles - p.full_tiles) * ksplit * BMr * BN * 4 < 0x7FFF0000ull)
+    p.cnt = tile_counters;
   p.div_hw = make_fastdiv(a.Hout * a.Wout);
   p.div_w = make_fastdiv(a.Wout);
   p.div_tn = make_fastdiv(p.tiles_n);
@@ -1120,7 +1194,7 @@ static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, int ar
 #undef LAUNCH_RS
 #undef LAUNCH_CONV
 #undef LAUNCH_CONV_
-  if (ksplit > 1) {
+  if (ksplit > 1 && !p.cnt) {
     const int Mt = a.M - p.tail_m0;  // rows covered by split tiles
     const int CV = (a.Nout + 3) / 4;
     int tpr = 1;
@@ -1156,7 +1230,7 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
                     int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad,
                     int dil, const float* bias, const float* scale, int relu, const float* add,
                     int ldadd, double* stats, int stats_nslot, int tile_n, int arith, float* scratch,
-                    size_t scratch_floats, hipStream_t stream) {
+                    size_t scratch_floats, unsigned int* tile_counters, hipStream_t stream) {
   if (!x || !w_fwd || !y || Ci % 32 != 0 || (ldx & 3) || !tile_code_ok(tile_n) || !arith_ok(arith))
     return SEMSEG_EINVAL;
   ConvArgs a;
@@ -1174,13 +1248,13 @@ int semseg_conv_fwd(const float* x, int ldx, const float* w_fwd, float* y, int l
       return semseg_split_gemm_conv1x1_fwd(x, ldx, w_fwd, y, ldy, a.M, Ci, Co, stats, a.stats_nslot, tile_n == 3128 ? 128 : 256, stream);
     tile_n = 128;
   }
-  return conv_launch(false, a, tile_n, arith, scratch, scratch_floats, stream);
+  return conv_launch(false, a, tile_n, arith, scratch, scratch_floats, tile_counters, stream);
 }
 
 static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
                       int pad, int dil, const float* add, int ldadd, int tile_n, int arith, const ConvArgs* bnr,
-                      float* scratch, size_t scratch_floats, hipStream_t stream) {
+                      float* scratch, size_t scratch_floats, unsigned* tile_counters, hipStream_t stream) {
   if (!dy || !w_dgrad || !dx || (lddy & 3) || !tile_code_ok(tile_n) || !arith_ok(arith)) return SEMSEG_EINVAL;
   const int Kc = (Co + 31) / 32 * 32;
   if (lddy < Kc) return SEMSEG_EINVAL;
@@ -1219,15 +1293,15 @@ static int dgrad_impl(const float* dy, int lddy, const float* w_dgrad, float* dx
       a.bnr_invstd[b] = bnr->bnr_invstd[b]; a.bnr_sums[b] = bnr->bnr_sums[b];
     }
   }
-  return conv_launch(true, a, tile_n, arith, scratch, scratch_floats, stream);
+  return conv_launch(true, a, tile_n, arith, scratch, scratch_floats, tile_counters, stream);
 }
 
 int semseg_conv_dgrad(const float* dy, int lddy, const float* w_dgrad, float* dx, int lddx, int N,
                       int H, int W, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
                       int pad, int dil, const float* add, int ldadd, int tile_n, int arith, float* scratch,
-                      size_t scratch_floats, hipStream_t stream) {
+                      size_t scratch_floats, unsigned int* tile_counters, hipStream_t stream) {
   return dgrad_impl(dy, lddy, w_dgrad, dx, lddx, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, add, ldadd, tile_n,
-                    arith, nullptr, scratch, scratch_floats, stream);
+                    arith, nullptr, scratch, scratch_floats, tile_counters, stream);
 }
 
 // Data gradient + the BatchNorm-backward reduction of the layer(s) that PRODUCED this conv's input, in one kernel:
@@ -1240,7 +1314,8 @@ int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, 
                                const unsigned* relu_bits, int ldbits,
                                const float* y0, int ldy0, const float* mean0, const float* invstd0, double* sums0,
                                const float* y1, int ldy1, const float* mean1, const float* invstd1, double* sums1,
-                               int nslot, int arith, float* scratch, size_t scratch_floats, hipStream_t stream) {
+                               int nslot, int arith, float* scratch, size_t scratch_floats, unsigned int* tile_counters,
+                               hipStream_t stream) {
   if (bn_count < 1 || bn_count > 2 || !y0 || !mean0 || !invstd0 || !sums0 || nslot < 1) return SEMSEG_EINVAL;
   if (bn_count == 2 && (!y1 || !mean1 || !invstd1 || !sums1)) return SEMSEG_EINVAL;
   // the fused path lives in the 16-byte store phase of the epilogue: everything 4-float aligned, channels % 4 == 0
@@ -1253,7 +1328,7 @@ int semseg_conv_dgrad_bnreduce(const float* dy, int lddy, const float* w_dgrad, 
   b.bnr_y[0] = y0; b.bnr_ldy[0] = ldy0; b.bnr_mean[0] = mean0; b.bnr_invstd[0] = invstd0; b.bnr_sums[0] = sums0;
   b.bnr_y[1] = y1; b.bnr_ldy[1] = ldy1; b.bnr_mean[1] = mean1; b.bnr_invstd[1] = invstd1; b.bnr_sums[1] = sums1;
   return dgrad_impl(dy, lddy, w_dgrad, dx, lddx, N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad, dil, add, ldadd, tile_n,
-                    arith, &b, scratch, scratch_floats, stream);
+                    arith, &b, scratch, scratch_floats, tile_counters, stream);
 }
 
 // Batched GEMMs on the two matrix-core kernels — the PSA point-affinity contraction (torch.bmm at
@@ -1271,7 +1346,7 @@ int semseg_gemm_rows_batched(const float* a, int lda, long long a_bs, const floa
   g.Kc = K; g.Nout = Nout; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.dil = 1;
   g.M = M; g.tiles_n = 0; g.stats_nslot = 1;
   g.batch = batch; g.x_bs = a_bs; g.w_bs = bt_bs; g.y_bs = c_bs; g.add_bs = 0; g.bnr_n = 0; g.bnr_mask = nullptr; g.bnr_bits = nullptr;
-  return conv_launch(false, g, Nout >= 128 ? 128 : 64, arith, nullptr, 0, stream);
+  return conv_launch(false, g, Nout >= 128 ? 128 : 64, arith, nullptr, 0, nullptr, stream);
 }
 
 }  // extern "C"

@@ -119,21 +119,26 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
+// dw[i] (=|+=) sum over the slabs of partial[slab][n]: 8 outputs per workgroup, 32 lanes per output each summing every 32nd slab (two
+// loads in flight), then a fixed-order fold over the 32 lanes — the first form walked all slabs per thread: 237 dependent
+// trips at per-GPU batch 2, 74 us for 6.5 MB.
 __global__ __launch_bounds__(256) void stem_wgrad_fold_kernel(const float* __restrict__ partial, int slabs, int n,
                                                               float* __restrict__ dw, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  int s = 0;
-  for (; s + 3 < slabs; s += 4) {
-    v0 += partial[(size_t)s * n + i];
-    v1 += partial[(size_t)(s + 1) * n + i];
-    v2 += partial[(size_t)(s + 2) * n + i];
-    v3 += partial[(size_t)(s + 3) * n + i];
+  const int l = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+  float v0 = 0.f, v1 = 0.f;
+  if (i < n) {
+    int s = l;
+    for (; s + 32 < slabs; s += 64) {
+      v0 += partial[(size_t)s * n + i];
+      v1 += partial[(size_t)(s + 32) * n + i];
+    }
+    if (s < slabs) v0 += partial[(size_t)s * n + i];
   }
-  for (; s < slabs; ++s) v0 += partial[(size_t)s * n + i];
-  const float v = (v0 + v1) + (v2 + v3);
-  dw[i] = accumulate ? dw[i] + v : v;
+  float v = v0 + v1;
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if (i < n && l == 0) dw[i] = accumulate ? dw[i] + v : v;
 }
 
 }  // namespace
@@ -171,7 +176,7 @@ int semseg_stem_conv_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_
   if (scratch_floats < (size_t)grid * 27 * 64) return SEMSEG_EINVAL;
   const int tiles_w = (Wo + STEM_SW - 1) / STEM_SW;
   stem_wgrad_kernel<64><<<grid, 256, 0, stream>>>(x_nchw, dy_nhwc, scratch, N, H, W, Ho, Wo, tiles_w, N * Ho * tiles_w);
-  stem_wgrad_fold_kernel<<<(27 * 64 + 255) / 256, 256, 0, stream>>>(scratch, grid, 27 * 64, dw_oihw, accumulate);
+  stem_wgrad_fold_kernel<<<(27 * 64 + 7) / 8, 256, 0, stream>>>(scratch, grid, 27 * 64, dw_oihw, accumulate);
   return semseg_launch_status();
 }
 

@@ -208,6 +208,23 @@ def _scr(scratch):
     return (None, 0) if scratch is None else (scratch.data_ptr(), scratch.numel())
 
 
+TILE_COUNTERS = 4096      # SEMSEG_TILE_COUNTERS of include/semseg_hip.h
+_CNT = {}
+FUSED_SPLIT = _os.environ.get("SEMSEG_FUSED_SPLIT", "1") != "0"      # 0: split tiles reduced by the separate launch of rounds 1-5 (A/B)
+
+
+def _cnt(scratch):
+    """The tile counters that go with a split-K scratch arena (same owner: the stream the arena belongs to): zeroed once, left zero
+    by every launch.  Allocated on first use of the arena — in the launch-by-launch steps in front of a recorded step plan."""
+    if scratch is None or not FUSED_SPLIT:
+        return None
+    key = (scratch.device.index, scratch.data_ptr())
+    t = _CNT.get(key)
+    if t is None:
+        t = _CNT[key] = torch.zeros(TILE_COUNTERS, dtype=torch.int32, device=scratch.device)
+    return t.data_ptr()
+
+
 def conv_pack_weights_multi(descs_dev, starts_dev, nconv, total_blocks):
     _ck(lib.semseg_conv_pack_weights_multi(_p(descs_dev), _p(starts_dev), nconv, total_blocks, _stream()),
         "conv_pack_weights_multi")
@@ -223,12 +240,12 @@ def conv_fwd(x, ldx, pk, y, ldy, N, H, W, stride, pad, dil, bias=None, add=None,
                        N * Ho * Wo * ldt,
                        lambda t, out: lib.semseg_conv_fwd(
                            _p(x), ldx, _p(pk.w_fwd), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
-                           pad, dil, None, None, 0, None, 0, _p(tstats), NSLOT, t, arith, *_scr(scratch), _stream()), arith)
+                           pad, dil, None, None, 0, None, 0, _p(tstats), NSLOT, t, arith, *_scr(scratch), _cnt(scratch), _stream()), arith)
     tile = plain_tile(tile, tile_key("fwd", N, H, W, pk.Ci, pk.Co, pk.R, pk.S, stride, pad, dil) + "|sp", pk.tile_fwd,
                       bias is None and scale is None and not relu and add is None)
     _ck(lib.semseg_conv_fwd(_p(x), ldx, _p(pk.w_fwd), _p(y), ldy, N, H, W, pk.Ci, Ho, Wo, pk.Co,
                             pk.R, pk.S, stride, pad, dil, _p(bias), _p(scale), int(relu), _p(add), ldadd,
-                            _p(stats), nslot, tile, arith, *_scr(scratch), _stream()), "conv_fwd")
+                            _p(stats), nslot, tile, arith, *_scr(scratch), _cnt(scratch), _stream()), "conv_fwd")
     return Ho, Wo
 
 
@@ -261,12 +278,12 @@ def _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch, 
                            lambda t, out: lib.semseg_conv_dgrad_bnreduce(
                                _p(dy), lddy, _p(pk.w_dgrad), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S, stride,
                                pad, dil, _p(addt), C, t, 1, None, 0, _p(bits), C // 32, _p(ybn), C, _p(mean), _p(invstd),
-                               _p(sums), None, 0, None, None, None, NSLOT, arith, *_scr(scratch), _stream()), arith)
+                               _p(sums), None, 0, None, None, None, NSLOT, arith, *_scr(scratch), _cnt(scratch), _stream()), arith)
     return _tuned_tile(key, pk.tile_dgrad, dy.device,
                        N * H * W * ldt,
                        lambda t, out: lib.semseg_conv_dgrad(
                            _p(dy), lddy, _p(pk.w_dgrad), _p(out), ldt, N, H, W, pk.Ci, Ho, Wo, pk.Co, pk.R, pk.S,
-                           stride, pad, dil, None, 0, t, arith, *_scr(scratch), _stream()), arith)
+                           stride, pad, dil, None, 0, t, arith, *_scr(scratch), _cnt(scratch), _stream()), arith)
 
 
 def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldadd=0, scratch=None, arith=ARITH_F32):
@@ -275,7 +292,7 @@ def conv_dgrad(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, add=None, ldad
     tile = _dgrad_tile(dy, lddy, pk, lddx, N, H, W, Ho, Wo, stride, pad, dil, scratch, arith)
     _ck(lib.semseg_conv_dgrad(_p(dy), lddy, _p(pk.w_dgrad), _p(dx), lddx, N, H, W, pk.Ci, Ho, Wo,
                               pk.Co, pk.R, pk.S, stride, pad, dil, _p(add), ldadd, tile, arith,
-                              *_scr(scratch), _stream()), "conv_dgrad")
+                              *_scr(scratch), _cnt(scratch), _stream()), "conv_dgrad")
 
 
 def conv_dgrad_bnreduce(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, act, ldact, bns, nslot, add=None, ldadd=0,
@@ -293,7 +310,7 @@ def conv_dgrad_bnreduce(dy, lddy, pk, dx, lddx, N, H, W, stride, pad, dil, act, 
                                        _p(relu_bits), 0 if relu_bits is None else relu_bits.shape[-1],
                                        _p(b0[0]), b0[1], _p(b0[2]), _p(b0[3]), _p(b0[4]),
                                        _p(b1[0]), b1[1], _p(b1[2]), _p(b1[3]), _p(b1[4]), nslot, arith, *_scr(scratch),
-                                       _stream()), "conv_dgrad_bnreduce")
+                                       _cnt(scratch), _stream()), "conv_dgrad_bnreduce")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -625,7 +642,7 @@ def gemm_rows(a_ptr, lda, bt_ptr, c_ptr, ldc, M, K, Nout, add_ptr=None, ldadd=0,
     implicit-GEMM kernel on raw device pointers."""
     tile = 128 if Nout >= 128 else 64
     _ck(lib.semseg_conv_fwd(a_ptr, lda, bt_ptr, c_ptr, ldc, 1, M, 1, K, M, 1, Nout, 1, 1, 1, 0, 1, None,
-                            None, 0, add_ptr, ldadd, None, 1, tile, arith, None, 0, _stream()), "gemm_rows")
+                            None, 0, add_ptr, ldadd, None, 1, tile, arith, None, 0, None, _stream()), "gemm_rows")
 
 
 def gemm_kmajor(x_ptr, ldx, y_ptr, ldy, out_ptr, scratch, K, Ci, Co, accumulate=False, arith=ARITH_F32):

@@ -30,7 +30,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     from semseg_amd._lib import lib
     assert lib.semseg_psamask_forward(0, None, None, 1, 1, 1, 1, 1, 0, 0, None) == -1
     assert lib.semseg_conv_fwd(None, 0, None, None, 0, 1, 1, 1, 32, 1, 1, 32, 1, 1, 1, 0, 1, None, None, 0, None,
-                               0, None, 1, 64, 0, None, 0, None) == -1
+                               0, None, 1, 64, 0, None, 0, None, None) == -1
     assert lib.semseg_sgd_step(None, None, None, 4, 0.1, None, 0.9, 0.0, 1.0, 1, None, None) == -1
 
 

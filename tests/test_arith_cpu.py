@@ -21,7 +21,7 @@ def test_library_has_no_process_wide_switch_and_rejects_unknown_codes():
     # so use distinct failure reasons: Ci % 32)
     fake = ctypes.c_void_p(4096)
     args = lambda arith, ci=32: (fake, 32, fake, fake, 32, 1, 1, 1, ci, 1, 1, 32, 1, 1, 1, 0, 1, None, None, 0, None, 0,
-                                 None, 1, 64, arith, None, 0, None)
+                                 None, 1, 64, arith, None, 0, None, None)
     for bad in (1, 2, 6, -1, 7):
         assert lib.semseg_conv_fwd(*args(bad)) == -1
     assert lib.semseg_gemm_rows_batched(fake, 32, 0, fake, 0, fake, 32, 0, 1, 32, 32, 1, 5, None) == -1

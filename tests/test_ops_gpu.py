@@ -1230,3 +1230,77 @@ def test_conv_arith_bf16x3_3x3(case, report):
     report("conv 3x3 split mode %s: forward rms %.2e (fp32 %.2e)  data gradient %.2e (fp32 %.2e)"
            % (case, res[True][0], res[False][0], res[True][1], res[False][1]))
     assert res[True][0] <= 2 * res[False][0] + 1e-7 and res[True][1] <= 2 * res[False][1] + 1e-7
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, Ci, Co, k, stride, pad, dil
+    (2, 60, 60, 1024, 256, 1, 1, 0, 1),      # layer3 conv1 at per-GPU batch 2: 114 tiles of 128 x 128, four K slices
+    (2, 60, 60, 2048, 512, 1, 1, 0, 1),      # layer4 conv1
+    (2, 30, 30, 128, 128, 3, 1, 1, 1),       # 3x3, eight slices
+    (7, 60, 60, 64, 256, 3, 1, 2, 2),        # full tiles and a split stream-K tail in one launch
+    (2, 21, 21, 256, 150, 1, 1, 0, 1),       # a partial column tile
+])
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+def test_split_k_reduced_inside_the_launch_equals_the_separate_reduction(case, arith, report, monkeypatch):
+    """Split-K tiles of semseg_conv_fwd / semseg_conv_dgrad[_bnreduce] reduced by the last slice's workgroup (tile_counters given) vs by
+    splitk_epilogue_kernel (rounds 1-5): the slabs are summed in slice order in both, so outputs are BIT-identical; statistics / fused
+    sums differ only by the arrival order of their fp64 atomics.  Repeated: the arrival order of the slices varies run to run, the
+    result must not.  The counters must be left zero."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co, k, stride, pad, dil = case
+    ar = ops.ARITH_F32 if arith == "f32" else ops.ARITH_BF16X3
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).to(DEV)
+    pk = ops.PackedConv(Co, Ci, k, k, DEV)
+    pk.pack(w)
+    Ho, Wo = ops.conv_out(H, k, stride, pad, dil), ops.conv_out(W, k, stride, pad, dil)
+    ldy = ops.roundup(Co, 4)
+    scratch = torch.empty(32 * 1024 * 1024, device=DEV)
+    NS = ops.NSLOT
+    bias = torch.randn(Co, generator=g).to(DEV)
+
+    def fwd(fused, with_stats):
+        monkeypatch.setattr(ops, "FUSED_SPLIT", fused)
+        y = torch.full((N, Ho, Wo, ldy), float("nan"), device=DEV)
+        st = torch.zeros(NS * 2 * Co, dtype=torch.float64, device=DEV) if with_stats else None
+        ops.conv_fwd(x, Ci, pk, y, ldy, N, H, W, stride, pad, dil, stats=st, nslot=NS, scratch=scratch, arith=ar,
+                     bias=None if with_stats else bias)
+        return y, st
+    for with_stats in (True, False):
+        y0, st0 = fwd(False, with_stats)
+        for _ in range(6):
+            y1, st1 = fwd(True, with_stats)
+            assert torch.equal(y0[..., :Co], y1[..., :Co]), "forward %s: in-kernel reduction differs" % (case,)
+            if with_stats:
+                a, b = st0.view(NS, -1).sum(0), st1.view(NS, -1).sum(0)
+                assert float(((a - b).abs() / (b.abs() + 1e-30)).max()) < 1e-12
+    # data gradient with the fused BatchNorm-backward reduction (input channels of the dgrad = Ci must be % 32 for the bit mask)
+    if Ci % 32 == 0:
+        M = N * H * W
+        ldd = ops.roundup(Co, 128)
+        dy = torch.zeros(N, Ho, Wo, ldd, device=DEV)
+        dy[..., :Co] = torch.randn(N, Ho, Wo, Co, generator=g).to(DEV)
+        act = torch.relu(torch.randn(M, Ci, generator=g)).to(DEV)
+        bits = relu_bits(act.view(N, H, W, Ci))
+        ybn = (torch.randn(M, Ci, generator=g) * 2 + 0.5).to(DEV)
+        mean, inv = torch.randn(Ci, generator=g).to(DEV), (torch.rand(Ci, generator=g) + 0.5).to(DEV)
+        add0 = torch.randn(M, Ci, generator=g).to(DEV)
+
+        def dgrad(fused):
+            monkeypatch.setattr(ops, "FUSED_SPLIT", fused)
+            dx = add0.clone()
+            sums = torch.zeros(NS * 2 * Ci, dtype=torch.float64, device=DEV)
+            ops.conv_dgrad_bnreduce(dy, ldd, pk, dx, Ci, N, H, W, stride, pad, dil, None, 0, [(ybn, Ci, mean, inv, sums)], NS,
+                                    add=dx, ldadd=Ci, scratch=scratch, arith=ar, relu_bits=bits)
+            return dx, sums
+        d0, s0 = dgrad(False)
+        for _ in range(6):
+            d1, s1 = dgrad(True)
+            assert torch.equal(d0, d1), "data gradient %s: in-kernel reduction differs" % (case,)
+            a, b = s0.view(NS, -1).sum(0), s1.view(NS, -1).sum(0)
+            assert float(((a - b).abs() / (b.abs() + 1e-30)).max()) < 2e-5     # (the kernel epilogue sums 8 rows per lane in fp32 before fp64, the separate launch sums in fp64)
+    cnt = ops._CNT[(scratch.device.index, scratch.data_ptr())]
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum().item()) == 0, "tile counters not left at zero"
+    report("split-K reduced inside the launch %s [%s]: outputs bit-identical to the separate reduction launch, statistics equal to 1e-12, fused sums to 2e-5" % (case, arith))
