@@ -318,8 +318,12 @@ int semseg_label_check(const long long* label, size_t n, int C, int ignore_index
  * psanet.py:88-91); transpose_batched: out[b][c][r] = in[b][r][c], columns r >= R zero-filled. */
 int semseg_psamask_nhwc_forward(int psa_type, const float* mask, int ldm, float* aff, int lda, int N,
                                 int H, int W, int mH, int mW, hipStream_t stream);
+/* backward: dmask_prezeroed = 0: the whole [N*H*W, taps] block is defined (out-of-window taps written as 0: N * HW * taps * 4 bytes
+ * on top of the algorithmic 2 * 4 * N * (HW)^2); 1: the caller guarantees that the out-of-window taps of dmask ARE zero (a buffer zeroed
+ * once and written by nothing but this call: they are the same elements every time for a fixed geometry) and only the in-window taps
+ * are written — what the reference's CUDA kernel does after its zeros_like (lib/psa/functions/psamask.py:33, psamask_cuda.cu:58-106). */
 int semseg_psamask_nhwc_backward(int psa_type, const float* daff, int lda, float* dmask, int ldm,
-                                 int N, int H, int W, int mH, int mW, hipStream_t stream);
+                                 int N, int H, int W, int mH, int mW, int dmask_prezeroed, hipStream_t stream);
 int semseg_softmax_rows_fwd(const float* x, int ldx, float* y, int ldy, int rows, int P,
                             float alpha, int softmax, hipStream_t stream);
 int semseg_softmax_rows_bwd(const float* y, int ldy, const float* dy, int lddy, float* dx,

@@ -49,6 +49,10 @@ for (N, H, mH) in [(16, 30, 59), (16, 45, 89), (2, 30, 59)]:
         rows.append(("pixel-major", N, H, mH, typ, "fwd", tf, alg, alg))
         # backward writes the whole tap row (zeros included)
         rows.append(("pixel-major", N, H, mH, typ, "bwd", tb, alg, 4 * N * HW * HW + 4 * N * HW * ldm))
+        # the engine's form (round 6): gradient buffer zeroed once, only in-window taps written
+        dm.zero_()
+        tz = timeit(lambda: ops.psamask_nhwc_backward(typ, daff, P, dm, ldm, N, H, W, mH, mW, prezeroed=True))
+        rows.append(("px-major 0'd", N, H, mH, typ, "bwd", tz, alg, alg))
 print("%-12s %3s %3s %3s %4s %4s %9s %12s %10s %12s %10s" % ("form", "N", "H", "mH", "type", "dir", "us", "alg MB", "alg TB/s",
                                                            "moved MB", "moved TB/s"))
 for form, N, H, mH, typ, d, t, alg, moved in rows:

@@ -118,6 +118,23 @@ __global__ __launch_bounds__(256) void psamask_nhwc_bwd_distribute_kernel(const 
   }
 }
 
+// Collect with a pre-zeroed destination (round 6): lanes run along the SOURCE positions b of row a of dA (one coalesced read of the
+// row) and every lane stores its value at its tap — runs of W contiguous taps per image row; out-of-window taps are neither
+// computed nor written (the engine's gradient buffer of the attention map is zeroed once: its out-of-window taps are the same
+// elements every step).  Bytes moved = 2 * 4 * N * (HW)^2, the algorithmic figure (the full-row form writes N * HW * taps more).
+__global__ __launch_bounds__(256) void psamask_nhwc_bwd_collect_sparse_kernel(const PsaNhwcArgs p) {
+  const int HW = p.H * p.W;
+  const int a = blockIdx.x % HW, n = blockIdx.x / HW;
+  const int ha = a / p.W, wa = a - ha * p.W;
+  const float* src = p.src + ((size_t)n * HW + a) * p.lds_;
+  float* dst = p.dst + ((size_t)n * HW + a) * p.ldd;
+  for (int b = threadIdx.x; b < HW; b += 256) {
+    const int hb = b / p.W, wb = b - hb * p.W;
+    const int hi = hb - ha + p.hh, wi = wb - wa + p.hw;
+    if ((unsigned)hi < (unsigned)p.mH && (unsigned)wi < (unsigned)p.mW) dst[hi * p.mW + wi] = src[b];
+  }
+}
+
 __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
@@ -220,15 +237,16 @@ int semseg_psamask_nhwc_forward(int psa_type, const float* mask, int ldm, float*
 }
 
 int semseg_psamask_nhwc_backward(int psa_type, const float* daff, int lda, float* dmask, int ldm,
-                                 int N, int H, int W, int mH, int mW, hipStream_t stream) {
+                                 int N, int H, int W, int mH, int mW, int dmask_prezeroed, hipStream_t stream) {
   if (!daff || !dmask || lda < H * W || ldm < mH * mW || N <= 0) return SEMSEG_EINVAL;
   const int tiles = (H * W + PT - 1) / PT;
   PsaNhwcArgs a{daff, dmask, lda, ldm, psa_type ? 1 : 0, N, H, W, mH, mW, (mH - 1) / 2, (mW - 1) / 2, tiles};
   if (!psa_type) {
-    psamask_nhwc_bwd_collect_kernel<<<N * H * W, 256, 0, stream>>>(a);
+    if (dmask_prezeroed) psamask_nhwc_bwd_collect_sparse_kernel<<<N * H * W, 256, 0, stream>>>(a);
+    else psamask_nhwc_bwd_collect_kernel<<<N * H * W, 256, 0, stream>>>(a);
   } else {
-    // out-of-window taps are zero: clear the [N*H*W, ldm] block, then scatter the in-window tiles
-    if (hipMemsetAsync(dmask, 0, (size_t)N * H * W * ldm * sizeof(float), stream) != hipSuccess) return SEMSEG_ELAUNCH;
+    // out-of-window taps are zero: clear the [N*H*W, ldm] block (unless the caller keeps them zero), then scatter the in-window tiles
+    if (!dmask_prezeroed && hipMemsetAsync(dmask, 0, (size_t)N * H * W * ldm * sizeof(float), stream) != hipSuccess) return SEMSEG_ELAUNCH;
     const long long grid = (long long)N * tiles * tiles;
     if (grid > 2147483647LL) return SEMSEG_EINVAL;
     psamask_nhwc_bwd_distribute_kernel<<<(int)grid, 256, 0, stream>>>(a);

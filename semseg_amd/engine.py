@@ -138,18 +138,27 @@ RELU_BITS = os.environ.get("SEMSEG_RELU_BITS", "1") != "0"
 XCHG_HOST_OP = os.environ.get("SEMSEG_XCHG_HOST_OP", "0") == "1"
 WGRAD_EXACT_1X1_ONLY = os.environ.get("SEMSEG_WGRAD_EXACT_1X1_ONLY", "0") == "1"     # measurement: the long-reduction rule for 1x1 convs only
 WGRAD_BF16X3_MAX_M = int(os.environ.get("SEMSEG_WGRAD_BF16X3_MAX_M", "131072"))   # longer weight-gradient reductions: exact fp32 products
-# Round 6, small per-GPU batch: a BatchNorm layer whose tensor has few pixels gets few producer workgroups per statistics
-# address, so its [2C] fp64 vectors need 1-2 slot replicas instead of NSLOT — and with so few replicas the apply kernels can
-# derive scale / shift (and the parameter gradients) themselves: semseg_bn_apply_train / semseg_bn_bwd_apply_train, two
-# launches per layer and pass instead of four (SEMSEG_BN_FUSE_SMALL=0: the four-launch form everywhere; A/B).
-BN_FUSE_SMALL = os.environ.get("SEMSEG_BN_FUSE_SMALL", "0") != "0"
-BN_SMALL_M = (16384, 32768)       # pixels: <= [0] one replica, <= [1] two, above NSLOT (and the separate finalize kernels)
+# Round 6, small per-GPU batch: a BatchNorm layer is four launches per pass pair (statistics -> finalize -> apply; reduction -> parameter
+# gradients -> apply), the two middle ones ~5 us of pure latency each.  semseg_bn_apply_train / semseg_bn_bwd_apply_train derive scale /
+# shift (the sums of g) inside the apply launch: every thread folds the slot replicas of its 4 channels itself.  Taken where the
+# vector has ONE replica — behind a SyncBN all-reduce, i.e. on every layer of an N > 1 job (forced one-rank lines at per-GPU batch 2:
+# 22.56 -> 22.10 ms peer exchange, 22.97 -> 22.41 ms RCCL) — and never at a large batch, where the flat grid of the separate apply
+# kernel streams faster.  On one GPU the vectors keep their NSLOT replicas and the per-thread fold (nslot x 64 bytes of L2 reads per
+# thread) costs what the launch saves: 20.68 ms separate, 20.78-20.85 ms fused up to 256-512 channels, 21.03 up to 1024
+# (SEMSEG_BN_FUSE_MAX_CNS = channels x replicas bound; 0 = one replica only).  A first form cut the replicas to 1-2 so that every
+# layer qualified: the producers' same-address fp64 atomics then serialise, 21.7 -> 24.6 ms (profiles/r06_bs2_ab_notes.txt).
+# SEMSEG_BN_FUSE_SMALL=0: four launches everywhere.
+BN_FUSE_SMALL = os.environ.get("SEMSEG_BN_FUSE_SMALL", "1") != "0"
+BN_FUSE_MAX_M = int(os.environ.get("SEMSEG_BN_FUSE_MAX_M", "32768"))
+BN_FUSE_MAX_CNS = int(os.environ.get("SEMSEG_BN_FUSE_MAX_CNS", "0"))
 
 
 def nslot_for(M):
-    if not BN_FUSE_SMALL:
-        return ops.NSLOT
-    return 1 if M <= BN_SMALL_M[0] else (2 if M <= BN_SMALL_M[1] else ops.NSLOT)
+    return ops.NSLOT
+
+
+def bn_fuse_small(C, ns, M):
+    return BN_FUSE_SMALL and C % 4 == 0 and M <= BN_FUSE_MAX_M and (ns == 1 or C * ns <= BN_FUSE_MAX_CNS)
 
 
 def set_arith(name):
@@ -935,7 +944,7 @@ class Engine:
                     raise ValueError("Expected more than 1 value per channel when training, got input "
                                      "size [%d values per channel]" % cnt)
                 track = bm.track_running_stats and bm.running_mean is not None
-                if BN_FUSE_SMALL and fuse_ok and ns <= 2 and bl.C % 4 == 0:
+                if fuse_ok and bn_fuse_small(bl.C, ns, count):
                     bl.fin = (st, ns, cnt, track)
                     out.append(cnt)
                     continue
@@ -1033,7 +1042,7 @@ class Engine:
             group.todo = 1
         if not sync:
             group = None
-        if BN_FUSE_SMALL and group is None and len(members) == 1 and bl.ns <= 2 and bl.C % 4 == 0:
+        if group is None and len(members) == 1 and bn_fuse_small(bl.C, 1 if sync else bl.ns, y.M):
             # small tensor, one BatchNorm, no group: the parameter gradients ride in the backward apply launch (and the slot
             # replicas are folded there).  Under SyncBN it follows the all-reduce: the sums are global and every rank writes
             # global / world — what the gradient all-reduce + 1 / world makes of torch's per-rank local gradients too.

@@ -617,8 +617,8 @@ def psamask_nhwc_forward(psa_type, mask, ldm, aff, lda, N, H, W, mH, mW):
         "psamask_nhwc_forward")
 
 
-def psamask_nhwc_backward(psa_type, daff, lda, dmask, ldm, N, H, W, mH, mW):
-    _ck(lib.semseg_psamask_nhwc_backward(psa_type, _p(daff), lda, _p(dmask), ldm, N, H, W, mH, mW,
+def psamask_nhwc_backward(psa_type, daff, lda, dmask, ldm, N, H, W, mH, mW, prezeroed=False):
+    _ck(lib.semseg_psamask_nhwc_backward(psa_type, _p(daff), lda, _p(dmask), ldm, N, H, W, mH, mW, int(prezeroed),
                                          _stream()), "psamask_nhwc_backward")
 
 

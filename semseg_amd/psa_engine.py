@@ -86,6 +86,10 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
                                     hw, C, hw, N, accumulate=xs.ginit)
             eng._t1(ev)
             xs.ginit = True
+            if ym.grad is None and not psa.compact:
+                # zeroed ONCE (Engine.buf keeps it for the life of the engine) and written by the psamask backward only, which touches
+                # the in-window taps: the out-of-window taps of a fixed geometry are the same elements every step
+                ym.grad = eng.buf((ym.N, ym.H, ym.W, ym.ld), zero=True, tag="g:psa_ym")
             gym = eng.grad_of(ym)
             if psa.compact and typ == 0:
                 ops.softmax_rows_bwd(aff, P, daff, P, gym, ym.ld, N * hw, hw, alpha, psa.psa_softmax)
@@ -94,7 +98,7 @@ def _branch(eng, x4, red, att, typ, psa, zcat, zoff):
                 if psa.compact:
                     ops.transpose_batched(daff, P, hw * P, gym, ym.ld, hw * ym.ld, N, hw, hw)
                 else:
-                    ops.psamask_nhwc_backward(typ, daff, P, gym, ym.ld, N, h, w, mH, mW)
+                    ops.psamask_nhwc_backward(typ, daff, P, gym, ym.ld, N, h, w, mH, mW, prezeroed=True)
             ym.ginit = True
         # appended last => runs first in backward, before the attention convs' backward
         eng.push("psa_contract", bwd_contract, xs=xs, ym=ym, aff=aff, zcat=zcat, zoff=zoff, typ=typ, psa=psa, P=P,

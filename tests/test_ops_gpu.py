@@ -412,7 +412,7 @@ def test_bn_train_fwd_bwd(C, HW, mode, report):
     assert max(errs) < 2e-5
 
 
-@pytest.mark.parametrize("C,HW,N,ns", [(64, 13, 3, 1), (256, 60, 2, 1), (1024, 9, 2, 2), (2048, 5, 2, 2), (512, 6, 1, 1)])
+@pytest.mark.parametrize("C,HW,N,ns", [(64, 13, 3, 1), (256, 60, 2, 1), (1024, 9, 2, 2), (2048, 5, 2, 2), (512, 6, 1, 1), (256, 60, 2, 8), (512, 30, 2, 8), (64, 119, 2, 8)])
 @pytest.mark.parametrize("mode", ["plain", "res", "drop"])
 def test_bn_fused_train_launches_equal_the_separate_ones(C, HW, N, ns, mode, report):
     """semseg_bn_apply_train == semseg_bn_finalize + semseg_bn_apply and semseg_bn_bwd_apply_train == semseg_bn_param_grads +
@@ -716,6 +716,12 @@ def test_psamask_nhwc_vs_oracle(H, W, mH, mW, report):
         ops.psamask_nhwc_backward(t, da, lda, dm, ldm, N, H, W, mH, mW)
         gotb = dm[:, :T].view(N, H, W, T).permute(0, 3, 1, 2)
         assert np.array_equal(gotb.cpu().numpy(), ref_b), "bwd type %d" % t
+        # pre-zeroed destination: only in-window taps are written, twice in a row (stale in-window values are overwritten)
+        dz = torch.zeros(N * HW, ldm, device=DEV)
+        ops.psamask_nhwc_backward(t, da * 2, lda, dz, ldm, N, H, W, mH, mW, prezeroed=True)
+        ops.psamask_nhwc_backward(t, da, lda, dz, ldm, N, H, W, mH, mW, prezeroed=True)
+        assert np.array_equal(dz[:, :T].view(N, H, W, T).permute(0, 3, 1, 2).cpu().numpy(), ref_b), "bwd type %d, pre-zeroed" % t
+        assert float(dz[:, T:].abs().sum()) == 0.0
     report("psamask nhwc H=%d W=%d mask %dx%d bit-exact" % (H, W, mH, mW))
 
 
