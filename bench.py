@@ -293,7 +293,7 @@ def trainer_leg(args, dev, world, rank, B, steps, warmup, arith, kernel_timing, 
         if dist_on:      # which SyncBN exchange the job took, and why (peer-memory kernel after its start-up self-test, or RCCL)
             from semseg_amd import syncbn_xchg
             out["syncbn_exchange"] = syncbn_xchg.DECISION.get(dev.index, (None, "no SyncBN exchange was issued"))[1]
-        out["step_driver"] = {"timed_steps_replayed_from_C": min(replayed, steps), "hip_graph": bool(tr.use_graph),
+        out["step_driver"] = {"timed_steps_replayed_from_C": min(replayed, steps),
                               "log": tr.plan_log[-1:] if tr.use_plan else ["SEMSEG_STEP_PLAN=0: launch by launch from Python"]}
         for e in tr.engines.values():
             e.check_labels()

@@ -425,15 +425,13 @@ int semseg_sgd_step(float* w, const float* g, float* mom, size_t n, float lr, co
  * entry point (semseg_plan_fn_id of its name) + one 64-bit slot per argument: pointers / integers / hipStream_t by value
  * (integers sign-extended), float / double by bit pattern in the low 32 / all 64 bits — and replays them from C:
  * semseg_plan_replay calls entries [first, last) in order and stops at the first non-zero return code (returned;
- * semseg_plan_failed_entry names the entry).  semseg_plan_graph_capture captures the same replay into a hipGraph owned by the
- * plan (returns its id >= 0; `origin` = the non-default stream the range starts and ends on, other streams joined through
- * semseg_stream_wait_stream), semseg_plan_graph_launch launches it.  A range that contains a collective is replayed in
+ * semseg_plan_failed_entry names the entry).  A range that contains a collective is replayed in
  * segments around it.  Per-step values live in device memory: semseg_step_state_set writes {lr, lr_head} (read by
  * semseg_sgd_step through lr_dev) and the dropout call offset (semseg_dropout2d_mask's offset_dev) on the stream.
  * A driver accepts a record only when the NEXT step, recorded the same way, holds the same calls (semseg_plan_compare): a
  * step whose launch sequence depends on anything but the recorded arguments is never replayed.
  * semseg_plan_* entry points themselves cannot be recorded.  semseg_stream_wait_stream(waiter, signaller): work enqueued on
- * `waiter` afterwards runs after the work enqueued on `signaller` so far (event record + wait; a graph edge under capture).
+ * `waiter` afterwards runs after the work enqueued on `signaller` so far (event record + wait).
  * semseg_host_probe: host-only, stores its arguments in host_out[0..5] and counts calls in host_out[6]; returns
  * SEMSEG_EINVAL for a == -12345 (tests of the slot encoding on machines without a GPU). */
 int semseg_plan_create(void** plan);
@@ -448,9 +446,6 @@ int semseg_plan_get_slot(void* plan, int entry, int arg, unsigned long long* bit
 int semseg_plan_compare(void* plan_a, void* plan_b, int ignore_fn, int ignore_arg, int* where);   /* 0 equal; 1 differ at entry where[0], argument where[1] (-1: entry point / count); argument ignore_arg of entry point ignore_fn is not compared */
 int semseg_plan_replay(void* plan, int first, int last);
 int semseg_plan_failed_entry(void* plan);
-int semseg_plan_graph_capture(void* plan, int first, int last, hipStream_t origin);
-int semseg_plan_graph_launch(void* plan, int graph, hipStream_t stream);
-int semseg_plan_graph_nodes(void* plan, int graph);
 int semseg_stream_wait_stream(hipStream_t waiter, hipStream_t signaller);
 int semseg_step_state_set(float* lr_dev2, float lr, float lr_head, unsigned long long* drop_dev,
                           unsigned long long drop_offset, hipStream_t stream);

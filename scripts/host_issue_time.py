@@ -1,7 +1,7 @@
-"""Host-side issue time of a train step against its GPU time, for the three step drivers:
+"""Host-side issue time of a train step against its GPU time, for the two step drivers:
   eager  Python sequences every launch through ctypes (rounds 1-4)
   plan   recorded once, replayed by one semseg_plan_replay call (csrc/plan.hip)
-  graph  the same record captured into one hipGraph (semseg_plan_graph_launch)
+(a third, one hipGraph of the record, was measured in rounds 5-6 and removed: profiles/r06_host_issue_b2.json)
 host ms = wall time of the python thread inside Trainer.step with an idle queue in front of it (synchronize before every
 step: nothing to wait for but the issue itself); device ms = back-to-back steps.   python scripts/host_issue_time.py [batch] [out.json]"""
 import json, os, sys, time
@@ -19,11 +19,11 @@ if DIST:
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
     res["path"] = "N > 1 code path on one rank, SyncBN exchange " + os.environ.get("SEMSEG_SYNCBN_XCHG", "0")
-for mode in (("eager", "plan") if DIST else ("eager", "plan", "graph")):
+for mode in ("eager", "plan"):
     torch.manual_seed(0)
     m = PSPNet(layers=101, classes=150, zoom_factor=8, pretrained=False).cuda().train()
     tr = Trainer(m, base_lr=0.01, sync_bn=True)
-    tr.use_plan, tr.use_graph = mode != "eager", mode == "graph"
+    tr.use_plan = mode != "eager"
     x = torch.randn(B, 3, 473, 473).cuda()
     y = torch.randint(0, 150, (B, 473, 473)).cuda()
     for _ in range(6):

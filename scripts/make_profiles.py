@@ -83,7 +83,7 @@ with open(os.path.join(ROOT, "profiles", tag + "_bench_family_stats.csv"), "w") 
     fo.write("family,calls,total_ms,avg_us\n")
     for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         fo.write('"%s",%d,%.3f,%.2f\n' % (k, c, t / 1e6, t / c / 1e3))
-# serialized run (SEMSEG_SIDE_WGRAD=0 SEMSEG_HIPRI_MAIN=0): the durations the bench line's roofline is quoted on
+# serialized run (SEMSEG_DEBUG=side_wgrad=0,hipri_main=0): the durations the bench line's roofline is quoted on
 sp = os.path.join(g, tag + "_serial", "bench_kernel_stats.csv")
 if os.path.exists(sp):
     shutil.copy(sp, os.path.join(ROOT, "profiles", tag + "_serial_kernel_stats.csv"))

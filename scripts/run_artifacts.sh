@@ -18,7 +18,7 @@ timeout 300 python bench.py --size 713 --classes 19 --global-batch 2 --steps 16 
 # BASELINE configs[3]: PSANet-101 465^2 batch 16
 timeout 400 python bench.py --arch psa --size 465 --steps 8 --warmup 2 --no-cpu-baseline --module-steps 0 > $out/${tag}_psanet.log 2>&1; line $out/${tag}_psanet.log > $out/${tag}_psanet.json
 # two-stream backward vs everything on one stream, final code
-timeout 300 python scripts/ab_libs.py $out/${tag}_two_stream_ab.json 16 2 two_stream one_stream::SEMSEG_SIDE_WGRAD=0+SEMSEG_HIPRI_MAIN=0 > $out/${tag}_two_stream_ab.log 2>&1
+timeout 300 python scripts/ab_libs.py $out/${tag}_two_stream_ab.json 16 2 two_stream one_stream::SEMSEG_DEBUG=side_wgrad=0,hipri_main=0 > $out/${tag}_two_stream_ab.log 2>&1
 # host issue time of the three step drivers (launch by launch / C replay / hipGraph) at per-GPU batch 2 and 16
 timeout 300 python scripts/host_issue_time.py 2 $out/${tag}_host_issue_b2.json > $out/${tag}_host_issue_b2.log 2>&1
 timeout 300 python scripts/host_issue_time.py 16 $out/${tag}_host_issue_b16.json > $out/${tag}_host_issue_b16.log 2>&1

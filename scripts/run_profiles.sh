@@ -12,7 +12,7 @@ grep "^{\"metric\"" $out/bench_${tag}_n1.log | tail -1 > $out/bench_${tag}_n1.js
 # the same command with every kernel on one stream: per-kernel durations without the side-stream concurrency (what the
 # bench line's roofline / kernel_families are measured on)
 rm -rf $out/${tag}_serial
-SEMSEG_SIDE_WGRAD=0 SEMSEG_HIPRI_MAIN=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_serial -o bench -- python bench.py $X --no-cpu-baseline --no-exact --module-steps 0 > $out/bench_${tag}_serial.log 2>&1
+SEMSEG_DEBUG=side_wgrad=0,hipri_main=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_serial -o bench -- python bench.py $X --no-cpu-baseline --no-exact --module-steps 0 > $out/bench_${tag}_serial.log 2>&1
 f=$(find $out/${tag}_serial -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && [ "$f" != "$out/${tag}_serial/bench_kernel_stats.csv" ] && cp "$f" $out/${tag}_serial/bench_kernel_stats.csv
 B="python bench.py $X --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-exact --module-steps 0"
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch -o pmc -- $B > $out/${tag}_fetch.log 2>&1

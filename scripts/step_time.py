@@ -1,6 +1,6 @@
 """One Trainer configuration, one JSON line: ms per train step (timed like bench.py, no barrier needed on one GPU) and — with
 FAMILIES=1 — the serialized per-family HIP-event table of two more steps.  Everything else comes from the environment
-(SEMSEG_HIP_LIB, SEMSEG_ARITH, SEMSEG_SIDE_WGRAD, ...), so that scripts/ab_libs.py can A/B libraries and switches process
+(SEMSEG_HIP_LIB, SEMSEG_ARITH, SEMSEG_DEBUG=side_wgrad=0,..., ...), so that scripts/ab_libs.py can A/B libraries and switches process
 by process.   python scripts/step_time.py [batch] [steps] [arch] [size] [classes]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

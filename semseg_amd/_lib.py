@@ -7,6 +7,18 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "semseg_hip.h")
+def debug(name, default=None):
+    """Value (a string) of the A/B switch `name` in the environment variable SEMSEG_DEBUG = "name=value,name=value,...", or
+    `default`.  Everything a measurement or a test toggles and a user never needs lives there (DESIGN.md section 10 lists the
+    names); what a user may set has a variable of its own: SEMSEG_ARITH, SEMSEG_SYNCBN_XCHG, SEMSEG_STEP_PLAN,
+    SEMSEG_CHECK_LABELS, SEMSEG_HIP_LIB (SEMSEG_FORCE_DIST / SEMSEG_TILE_TUNE: test and tuning drivers)."""
+    for item in os.environ.get("SEMSEG_DEBUG", "").split(","):
+        k, _, v = item.partition("=")
+        if k.strip() == name:
+            return v.strip()
+    return default
+
+
 LIB_PATH = os.environ.get("SEMSEG_HIP_LIB") or os.path.join(HERE, "csrc", "libsemseg_hip.so")  # override: kernel tuning only
 
 _CT = {

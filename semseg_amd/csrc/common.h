@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -19,6 +21,28 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 static inline int semseg_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEMSEG_OK : SEMSEG_ELAUNCH;
+}
+
+// A/B switch `name` of the environment variable SEMSEG_DEBUG = "name=value,name=value,..." (read per call: tests and tuning scripts
+// switch inside one process): its value copied into buf, or nullptr.  Nothing a user needs lives there.
+static inline const char* semseg_debug(const char* name, char* buf, size_t n) {
+  const char* e = getenv("SEMSEG_DEBUG");
+  if (!e) return nullptr;
+  const size_t ln = strlen(name);
+  while (*e) {
+    while (*e == ',' || *e == ' ') ++e;
+    const char* end = strchr(e, ',');
+    if (!end) end = e + strlen(e);
+    if ((size_t)(end - e) > ln && !strncmp(e, name, ln) && e[ln] == '=') {
+      size_t l = (size_t)(end - (e + ln + 1));
+      if (l >= n) l = n - 1;
+      memcpy(buf, e + ln + 1, l);
+      buf[l] = 0;
+      return buf;
+    }
+    e = end;
+  }
+  return nullptr;
 }
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {

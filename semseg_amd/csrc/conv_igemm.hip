@@ -1137,8 +1137,10 @@ static int conv_launch(bool transposed, const ConvArgs& a, int tile_code, int ar
   p.part = scratch;
   // In-kernel reduction of the split tiles (ConvArgs::cnt) when the caller gave tile counters: the last slice of a tile to finish
   // sums the others' register-layout slabs — a serial read of ksplit x 32-64 KB by one workgroup, against a separate launch that
-  // re-reads every partial sum from a [ksplit][M][N] array: taken up to FUSED_SPLIT_MAX slices per tile (SEMSEG_FUSED_SPLIT_MAX).
-  static const int fused_max = [] { const char* e = getenv("SEMSEG_FUSED_SPLIT_MAX"); return e ? atoi(e) : 16; }();
+  // re-reads every partial sum from a [ksplit][M][N] array: taken up to 16 slices per tile (SEMSEG_DEBUG fused_split_max).
+  char dbg_fm[16];
+  const char* fm_s = semseg_debug("fused_split_max", dbg_fm, sizeof(dbg_fm));
+  const int fused_max = fm_s ? atoi(fm_s) : 16;
   p.cnt = nullptr;
   if (ksplit > 1 && tile_counters && ksplit <= fused_max && (tiles - p.full_tiles) <= SEMSEG_TILE_COUNTERS &&
       (size_t)(tiles - p.full_tiles) * ksplit * BMr * BN <= scratch_floats &&

@@ -870,11 +870,12 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   // (a batched launch multiplies the grid by the batch: the 16 GEMMs of a Winograd weight gradient fill the chip with
   // 128 x 128 tiles where a single GEMM of that size would not)
   const bool small_tiles = batch == 1 && ((RS == 1 && t128 <= 16 && M < 32768) || (RS > 1 && t128 <= 36 && M < 8192));
-  const char* small_s = getenv("SEMSEG_WGRAD_SMALL");   // "0": never fall back to 64 x 64 tiles (tests / tuning)
+  char dbg_small[16], dbg_sp0[16], dbg_dma[64], dbg_sp64[16], dbg_sp[16];
+  const char* small_s = semseg_debug("wgrad_small", dbg_small, sizeof(dbg_small));   // "0": never fall back to 64 x 64 tiles (tests / tuning)
   const bool allow_small = !(small_s && small_s[0] == '0');
   const bool big = (Ci % 128 == 0) && (Co >= 128) && !(allow_small && small_tiles);
   // bf16x3 variant 10: the 128 x 256 kernel (64 x 128 wave tiles, one workgroup per CU); needs 256-channel column tiles
-  const char* sp_s0 = getenv("SEMSEG_WGRAD_SP");
+  const char* sp_s0 = semseg_debug("wgrad_sp", dbg_sp0, sizeof(dbg_sp0));
   const int sp_env0 = sp_s0 ? atoi(sp_s0) : WGRAD_SP_POLICY;
   const bool wide = big && arith == SEMSEG_ARITH_BF16X3 && sp_env0 == 10 && Ci % 256 == 0 &&
                     (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
@@ -901,7 +902,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   scratch_floats /= batch;   // every batch item owns its own slab set
   // Direct-to-LDS variants of the 128 x 128 kernel (1..5 = K-step / ring depth / residency; 0 = register-staged
   // kernel).  They need byte offsets below 2^31 for both operands.
-  // Variant choice.  SEMSEG_WGRAD_DMA = 0..5 forces one variant (read per call: tuning scripts switch inside one
+  // Variant choice.  SEMSEG_DEBUG wgrad_dma = 0..5 forces one variant (read per call: tuning scripts switch inside one
   // process); "a:b:t" = variant a for grids of <= t tiles, b above; unset = WGRAD_DMA_POLICY.  Measured at bs 16
   // (DESIGN.md section 8.2): kernel by kernel the three rings are within 1.5 % of each other (55.2-56.0 ms per
   // step vs 58.3 for the register-staged kernel; KS 32 best on the short 1x1 grids, KS 16 x 3 on cls.0), but inside
@@ -912,7 +913,7 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
 #endif
 
 
-  const char* dma_s = getenv("SEMSEG_WGRAD_DMA");
+  const char* dma_s = semseg_debug("wgrad_dma", dbg_dma, sizeof(dbg_dma));
   if (!dma_s) dma_s = WGRAD_DMA_POLICY;
   int dma_env = atoi(dma_s);
   if (const char* c1 = strchr(dma_s, ':')) {
@@ -923,14 +924,14 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
   }
   const bool dma_ok = (size_t)N * H * W * ldx * 4 < 0x7FFF0000ull && (size_t)M * lddy * 4 < 0x7FFF0000ull;
   const bool sp = big && arith == SEMSEG_ARITH_BF16X3;   // 128 x 128 tiles with split-bf16 products
-  // 64 x 64 tiles under bf16x3: the SP instance of the register-staged kernel (SEMSEG_WGRAD_SP64=0: the exact-fp32 kernel,
+  // 64 x 64 tiles under bf16x3: the SP instance of the register-staged kernel (SEMSEG_DEBUG wgrad_sp64=0: the exact-fp32 kernel,
   // what rounds 3-4 ran these tiles on)
-  const char* sp64_s = getenv("SEMSEG_WGRAD_SP64");
+  const char* sp64_s = semseg_debug("wgrad_sp64", dbg_sp64, sizeof(dbg_sp64));
   const bool sp64 = !big && arith == SEMSEG_ARITH_BF16X3 && !(sp64_s && sp64_s[0] == '0');
   // bf16x3 variants: 8 / 9 = the direct-to-LDS ring with the split at fragment time (4 stages, 2 workgroups per CU / 3
   // stages, 3 per CU); 10 (the policy) = the 128 x 256 kernel with 64 x 128 wave tiles for layers with Ci % 256 == 0 and
-  // variant 8 for the rest; 0 = the register-staged SP kernel of round 3.  SEMSEG_WGRAD_SP = 0 | 8 | 9 | 10 (A/B, tests).
-  const char* sp_s = getenv("SEMSEG_WGRAD_SP");
+  // variant 8 for the rest; 0 = the register-staged SP kernel of round 3.  SEMSEG_DEBUG wgrad_sp = 0 | 8 | 9 | 10 (A/B, tests).
+  const char* sp_s = semseg_debug("wgrad_sp", dbg_sp, sizeof(dbg_sp));
   const int sp_env = sp_s ? atoi(sp_s) : WGRAD_SP_POLICY;
   const int sp_dma = wide ? 10 : (sp && dma_ok && (sp_env == 8 || sp_env == 9 || sp_env == 10)) ? (sp_env == 10 ? 8 : sp_env) : 0;
   const int dma = sp ? sp_dma : ((big && dma_ok && dma_env >= 0 && dma_env <= 7) ? dma_env : 0);

@@ -4,13 +4,15 @@
 // entry points of include/semseg_hip.h on two or three HIP streams.  Their arguments — device pointers of buffers the engine
 // owns for its whole life, shapes, tile codes, stream handles — are the same every step, so the sequence is RECORDED once
 // (the host driver appends every call it makes: entry-point id + a row of 64-bit argument slots) and afterwards REPLAYED
-// from here: one C loop over call thunks (plan_thunks.inc, generated from the header), or — where the recorded range holds
-// no collective — one hipGraph captured from that loop.  What changes from step to step (learning rates, the dropout
+// from here: one C loop over call thunks (plan_thunks.inc, generated from the header).  (Rounds 5-6 could also capture that loop
+// into one hipGraph: measured twice, +5-10 % and +8-46 % on the device step — a graph's branches run on internal streams that
+// know nothing of the high-priority data-gradient chain — and removed in round 6; profiles/r06_host_issue_b2.json.)
+// What changes from step to step (learning rates, the dropout
 // counter) lives in device memory written by semseg_step_state_set before the replay; inputs are copied into buffers the
 // driver owns.  Cross-stream ordering (data-gradient chain vs weight-gradient side stream) is part of the record:
-// semseg_stream_wait_stream is an entry point like any other, and under capture its event pair becomes a graph edge.
+// semseg_stream_wait_stream is an entry point like any other.
 //
-// A plan holds no device memory and launches nothing by itself; destroying it frees its graphs.
+// A plan holds no device memory and launches nothing by itself.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -53,8 +55,6 @@ struct Plan {
   uint32_t magic = 0x504c414e;   // "PLAN"
   std::vector<Entry> entries;
   std::vector<unsigned long long> slots;
-  std::vector<hipGraphExec_t> graphs;
-  std::vector<int> graph_nodes;
   int failed = -1;
 };
 
@@ -63,19 +63,9 @@ inline Plan* as_plan(void* p) {
   return (pl && pl->magic == 0x504c414e) ? pl : nullptr;
 }
 
-// SEMSEG_PLAN_DEBUG=1: progress of a capture on stderr (which entry the runtime was in when something went wrong)
-bool plan_debug() {
-  static const bool on = [] { const char* v = std::getenv("SEMSEG_PLAN_DEBUG"); return v && v[0] == '1'; }();
-  return on;
-}
-
-int replay(Plan* pl, int first, int last, bool trace = false) {
+int replay(Plan* pl, int first, int last) {
   for (int i = first; i < last; ++i) {
     const Entry& e = pl->entries[i];
-    if (trace) {
-      std::fprintf(stderr, "[plan] entry %d %s\n", i, PLAN_THUNKS[e.fn].name);
-      std::fflush(stderr);
-    }
     const int rc = PLAN_THUNKS[e.fn].call(pl->slots.data() + e.off);
     if (rc != SEMSEG_OK) {
       pl->failed = i;
@@ -99,20 +89,6 @@ struct EventRing {
   }
 };
 thread_local EventRing g_events;
-
-// Under stream capture every wait gets an event of its own (never re-recorded inside one capture): the captured
-// dependency is then a plain record-node -> wait edge, whatever the runtime does with re-recorded events.  They are kept
-// for the life of the process (a capture makes a few hundred).
-struct CaptureEvents {
-  std::vector<hipEvent_t> ev;
-  hipEvent_t fresh() {
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    ev.push_back(e);
-    return e;
-  }
-};
-thread_local CaptureEvents g_capture_events;
 
 __global__ void step_state_kernel(float* lr2, float lr, float lr_head, unsigned long long* drop, unsigned long long off) {
   if (lr2) {
@@ -168,8 +144,6 @@ int semseg_plan_create(void** plan) {
 int semseg_plan_destroy(void* plan) {
   Plan* pl = as_plan(plan);
   if (!pl) return SEMSEG_EINVAL;
-  for (hipGraphExec_t g : pl->graphs)
-    if (g) (void)hipGraphExecDestroy(g);
   pl->magic = 0;
   delete pl;
   return SEMSEG_OK;
@@ -264,65 +238,10 @@ int semseg_plan_failed_entry(void* plan) {
   return pl ? pl->failed : SEMSEG_EINVAL;
 }
 
-// Captures the replay of entries [first, last) into one executable hipGraph owned by the plan.  `origin` must be a
-// non-default stream every other stream of the range is forked from (and joined back into) through semseg_stream_wait_stream.
-// Relaxed capture mode: other host threads (a data loader pinning memory, ...) stay free to call the runtime.
-int semseg_plan_graph_capture(void* plan, int first, int last, hipStream_t origin) {
-  Plan* pl = as_plan(plan);
-  if (!pl || !origin || first < 0 || last < first || last > (int)pl->entries.size()) return SEMSEG_EINVAL;
-  pl->failed = -1;
-  const bool dbg = plan_debug();
-  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
-  if (const char* m = std::getenv("SEMSEG_PLAN_CAPTURE_MODE")) {      // measurement / diagnosis only
-    if (m[0] == '0') mode = hipStreamCaptureModeGlobal;
-    if (m[0] == '1') mode = hipStreamCaptureModeThreadLocal;
-  }
-  if (dbg) std::fprintf(stderr, "[plan] begin capture of entries [%d, %d) mode %d\n", first, last, (int)mode);
-  if (hipStreamBeginCapture(origin, mode) != hipSuccess) return SEMSEG_ELAUNCH;
-  const int rc = replay(pl, first, last, dbg);
-  hipGraph_t graph = nullptr;
-  if (dbg) std::fprintf(stderr, "[plan] end capture (replay rc %d, failed entry %d)\n", rc, pl->failed);
-  const hipError_t e = hipStreamEndCapture(origin, &graph);
-  if (dbg) std::fprintf(stderr, "[plan] hipStreamEndCapture -> %d (%s)\n", (int)e, hipGetErrorString(e));
-  if (rc != SEMSEG_OK || e != hipSuccess || !graph) {
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipGetLastError();
-    return rc != SEMSEG_OK ? rc : SEMSEG_ELAUNCH;
-  }
-  size_t nodes = 0;
-  if (hipGraphGetNodes(graph, nullptr, &nodes) != hipSuccess) nodes = 0;
-  if (dbg) std::fprintf(stderr, "[plan] graph of %zu nodes, instantiating\n", nodes);
-  hipGraphExec_t exec = nullptr;
-  const hipError_t ei = hipGraphInstantiateWithFlags(&exec, graph, 0);
-  if (dbg) std::fprintf(stderr, "[plan] hipGraphInstantiateWithFlags -> %d (%s)\n", (int)ei, hipGetErrorString(ei));
-  (void)hipGraphDestroy(graph);
-  if (ei != hipSuccess || !exec) {
-    (void)hipGetLastError();
-    return SEMSEG_ELAUNCH;
-  }
-  pl->graphs.push_back(exec);
-  pl->graph_nodes.push_back((int)nodes);
-  return (int)pl->graphs.size() - 1;
-}
-
-int semseg_plan_graph_launch(void* plan, int graph, hipStream_t stream) {
-  Plan* pl = as_plan(plan);
-  if (!pl || graph < 0 || graph >= (int)pl->graphs.size() || !pl->graphs[graph]) return SEMSEG_EINVAL;
-  return hipGraphLaunch(pl->graphs[graph], stream) == hipSuccess ? SEMSEG_OK : SEMSEG_ELAUNCH;
-}
-
-int semseg_plan_graph_nodes(void* plan, int graph) {
-  Plan* pl = as_plan(plan);
-  if (!pl || graph < 0 || graph >= (int)pl->graphs.size()) return SEMSEG_EINVAL;
-  return pl->graph_nodes[graph];
-}
-
 // waiter: everything enqueued on it after this call runs after everything enqueued on `signaller` before this call.
 int semseg_stream_wait_stream(hipStream_t waiter, hipStream_t signaller) {
   if (waiter == signaller) return SEMSEG_OK;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  const bool capturing = signaller && hipStreamIsCapturing(signaller, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
-  hipEvent_t ev = capturing ? g_capture_events.fresh() : g_events.get();
+  hipEvent_t ev = g_events.get();
   if (!ev) return SEMSEG_ELAUNCH;
   if (hipEventRecord(ev, signaller) != hipSuccess) return SEMSEG_ELAUNCH;
   if (hipStreamWaitEvent(waiter, ev, 0) != hipSuccess) return SEMSEG_ELAUNCH;

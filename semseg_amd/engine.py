@@ -18,6 +18,7 @@ import torch.distributed as dist
 from torch import nn
 
 from . import ops
+from ._lib import debug
 
 F32 = torch.float32
 F64 = torch.float64
@@ -118,7 +119,7 @@ class Act:
 
 
 WINO_HBM = "wino_input / wino_output / wino_dy_wgrad / wino_filter_grad kernels (Winograd transforms, HBM-bound)"
-WINOGRAD = os.environ.get("SEMSEG_WINOGRAD", "1") != "0"   # 0: every 3x3 conv on the direct implicit-GEMM kernels (A/B)
+WINOGRAD = debug("winograd", "1") != "0"   # 0: every 3x3 conv on the direct implicit-GEMM kernels (A/B)
 # Arithmetic of the matrix-core products of every conv GEMM of an engine (include/semseg_hip.h):
 #   "bf16x3" (default)  SEMSEG_ARITH_BF16X3: each fp32 operand cut in flight into three bf16 pieces (all 24 mantissa bits),
 #                       six cross products on the bf16 matrix-core instruction, fp32 accumulation — fp32-grade by every
@@ -131,13 +132,13 @@ ARITH = _ARITH_NAMES[os.environ.get("SEMSEG_ARITH", "bf16x3")]
 # which kernel runs the 16 batched row GEMMs of a Winograd forward / data gradient under bf16x3: "standalone" (256 x 128
 # tiles, csrc/gemm_bf16split.hip; 197 vs 182 TFLOP/s fp32-equivalent on cls.0) or "igemm" (the SP instances of
 # conv_igemm_kernel that the 1x1 convs run)
-WINO_BF16X3_KERNEL = os.environ.get("SEMSEG_WINO_GEMM", "standalone")
-# SEMSEG_RELU_BITS=0: the fused BatchNorm-backward reductions read the post-ReLU activation as their mask (rounds 2-3) instead
+WINO_BF16X3_KERNEL = debug("wino_gemm", "standalone")
+# SEMSEG_DEBUG=relu_bits=0: the fused BatchNorm-backward reductions read the post-ReLU activation as their mask (rounds 2-3) instead
 # of the bit mask bn_apply writes next to it
-RELU_BITS = os.environ.get("SEMSEG_RELU_BITS", "1") != "0"
-XCHG_HOST_OP = os.environ.get("SEMSEG_XCHG_HOST_OP", "0") == "1"
-WGRAD_EXACT_1X1_ONLY = os.environ.get("SEMSEG_WGRAD_EXACT_1X1_ONLY", "0") == "1"     # measurement: the long-reduction rule for 1x1 convs only
-WGRAD_BF16X3_MAX_M = int(os.environ.get("SEMSEG_WGRAD_BF16X3_MAX_M", "131072"))   # longer weight-gradient reductions: exact fp32 products
+RELU_BITS = debug("relu_bits", "1") != "0"
+XCHG_HOST_OP = debug("xchg_host_op", "0") == "1"
+WGRAD_EXACT_1X1_ONLY = debug("wgrad_exact_1x1_only", "0") == "1"     # measurement: the long-reduction rule for 1x1 convs only
+WGRAD_BF16X3_MAX_M = int(debug("wgrad_bf16x3_max_m", "131072"))   # longer weight-gradient reductions: exact fp32 products
 # Round 6, small per-GPU batch: a BatchNorm layer is four launches per pass pair (statistics -> finalize -> apply; reduction -> parameter
 # gradients -> apply), the two middle ones ~5 us of pure latency each.  semseg_bn_apply_train / semseg_bn_bwd_apply_train derive scale /
 # shift (the sums of g) inside the apply launch: every thread folds the slot replicas of its 4 channels itself.  Taken where the
@@ -145,12 +146,12 @@ WGRAD_BF16X3_MAX_M = int(os.environ.get("SEMSEG_WGRAD_BF16X3_MAX_M", "131072")) 
 # 22.56 -> 22.10 ms peer exchange, 22.97 -> 22.41 ms RCCL) — and never at a large batch, where the flat grid of the separate apply
 # kernel streams faster.  On one GPU the vectors keep their NSLOT replicas and the per-thread fold (nslot x 64 bytes of L2 reads per
 # thread) costs what the launch saves: 20.68 ms separate, 20.78-20.85 ms fused up to 256-512 channels, 21.03 up to 1024
-# (SEMSEG_BN_FUSE_MAX_CNS = channels x replicas bound; 0 = one replica only).  A first form cut the replicas to 1-2 so that every
+# (SEMSEG_DEBUG bn_fuse_max_cns = channels x replicas bound; 0 = one replica only).  A first form cut the replicas to 1-2 so that every
 # layer qualified: the producers' same-address fp64 atomics then serialise, 21.7 -> 24.6 ms (profiles/r06_bs2_ab_notes.txt).
-# SEMSEG_BN_FUSE_SMALL=0: four launches everywhere.
-BN_FUSE_SMALL = os.environ.get("SEMSEG_BN_FUSE_SMALL", "1") != "0"
-BN_FUSE_MAX_M = int(os.environ.get("SEMSEG_BN_FUSE_MAX_M", "32768"))
-BN_FUSE_MAX_CNS = int(os.environ.get("SEMSEG_BN_FUSE_MAX_CNS", "0"))
+# SEMSEG_DEBUG=bn_fuse_small=0: four launches everywhere.
+BN_FUSE_SMALL = debug("bn_fuse_small", "1") != "0"
+BN_FUSE_MAX_M = int(debug("bn_fuse_max_m", "32768"))
+BN_FUSE_MAX_CNS = int(debug("bn_fuse_max_cns", "0"))
 
 
 def nslot_for(M):
@@ -333,7 +334,7 @@ class Engine:
         self.weights_version = None
         self.ktimer = None
         self._eval_epoch = 0
-        self.side_wgrad = os.environ.get("SEMSEG_SIDE_WGRAD", "1") == "1"
+        self.side_wgrad = debug("side_wgrad", "1") == "1"
         # Every weight gradient runs on the side stream (not only the small grids): the direct-to-LDS weight-gradient
         # kernel leaves >= 60 % of the VGPR file and 32 KB of LDS per CU free, so the HBM-bound BatchNorm backward
         # kernels and the data-gradient GEMMs of the main stream are co-resident with it instead of running alone
@@ -345,12 +346,12 @@ class Engine:
         # Not under torch.distributed: with the SyncBN all-reduces issued from the high-priority stream the forced
         # 1-rank RCCL step at batch 2 takes 60.5 ms instead of 39.2 (RCCL's own stream has normal priority and every
         # collective is an event round trip between the two).
-        self.hipri_main = os.environ.get("SEMSEG_HIPRI_MAIN", "1") == "1" and not self.dist_on
+        self.hipri_main = debug("hipri_main", "1") == "1" and not self.dist_on
         # number of weight-gradient streams used round-robin (each with its own split-K scratch); 2 / 3 / 4 measured
         # slower than 1
         self.n_side = 1
         # fold bn_bwd_reduce into the epilogue of the data gradient that completes a BatchNorm output's gradient
-        self.fuse_bnr = os.environ.get("SEMSEG_FUSE_BNR", "1") == "1"
+        self.fuse_bnr = debug("fuse_bnr", "1") == "1"
         self._sides, self._scr2s, self._side_rr = [], [], 0
         self._hi = None
         self._side = None
@@ -638,8 +639,8 @@ class Engine:
     def _wgrad_family(big, arith, Ci=0):
         if not big:
             return "conv_wgrad_kernel<64,64%s>+reduce" % _fam(arith)
-        # conv_wgrad.hip: WGRAD_SP_POLICY 10 = the 128 x 256 kernel for layers with Ci % 256 == 0 (SEMSEG_WGRAD_SP overrides)
-        if arith == ops.ARITH_BF16X3 and Ci % 256 == 0 and Ci > 0 and os.environ.get("SEMSEG_WGRAD_SP", "10") == "10":
+        # conv_wgrad.hip: WGRAD_SP_POLICY 10 = the 128 x 256 kernel for layers with Ci % 256 == 0 (SEMSEG_DEBUG wgrad_sp overrides)
+        if arith == ops.ARITH_BF16X3 and Ci % 256 == 0 and Ci > 0 and debug("wgrad_sp", "10") == "10":
             return "conv_wgrad_dma_wide_kernel<128x256,SP3>+reduce"
         return "conv_wgrad_dma_kernel<128x128%s>+reduce" % _fam(arith)
 

@@ -83,10 +83,11 @@ ARITH_BF16X3 = 3   # fp32 operands cut into three bf16 pieces in flight, six cro
 # ---------------------------------------------------------------------------------------------
 import json as _json
 import os as _os
+from ._lib import debug as _debug
 
 TILE_TABLE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tile_table.json")
 TILE_TUNE = _os.environ.get("SEMSEG_TILE_TUNE", "0") == "1"
-_FORCE_SPLIT_GEMM = _os.environ.get("SEMSEG_FORCE_SPLIT_GEMM", "0") == "1"    # measurement: every eligible shape on tile code 2128
+_FORCE_SPLIT_GEMM = _debug("force_split_gemm", "0") == "1"    # measurement: every eligible shape on tile code 2128
 
 
 def tile_key(kind, N, H, W, Ci, Co, R, S, stride, pad, dil):
@@ -158,10 +159,10 @@ TILE_CODES = (128, 64, 1128, 1064)   # 128x128, 128x64, 64x128, 64x64 (rows x co
 TILE_SPLIT_GEMM = 2128
 TILE_SPLIT_GEMM_128 = 3128     # the same kernel with 128 x 128 tiles (four waves): grids of a small per-GPU batch (round 5)
 SPLIT_GEMM_CODES = (TILE_SPLIT_GEMM, TILE_SPLIT_GEMM_128)
-_FORCE_SPLIT_CODE = TILE_SPLIT_GEMM_128 if _os.environ.get("SEMSEG_FORCE_SPLIT_GEMM_BM") == "128" else TILE_SPLIT_GEMM   # with _FORCE_SPLIT_GEMM
+_FORCE_SPLIT_CODE = TILE_SPLIT_GEMM_128 if _debug("force_split_gemm_bm") == "128" else TILE_SPLIT_GEMM   # with _FORCE_SPLIT_GEMM
 TILE_TIMES = {}   # key -> {tile code: ms per launch}, filled in tuning mode only
 # tile shapes measured with the SEMSEG_ARITH_BF16X3 instances of the kernels: keys suffixed "|sp"
-TILE_TABLE_SP_PATH = _os.environ.get("SEMSEG_TILE_TABLE_SP") or TILE_TABLE_PATH.replace("tile_table.json", "tile_table_sp.json")
+TILE_TABLE_SP_PATH = _debug("tile_table_sp") or TILE_TABLE_PATH.replace("tile_table.json", "tile_table_sp.json")
 TILE_CHOICE = _load_tables()
 
 
@@ -210,7 +211,7 @@ def _scr(scratch):
 
 TILE_COUNTERS = 4096      # SEMSEG_TILE_COUNTERS of include/semseg_hip.h
 _CNT = {}
-FUSED_SPLIT = _os.environ.get("SEMSEG_FUSED_SPLIT", "1") != "0"      # 0: split tiles reduced by the separate launch of rounds 1-5 (A/B)
+FUSED_SPLIT = _debug("fused_split", "1") != "0"      # 0: split tiles reduced by the separate launch of rounds 1-5 (A/B)
 
 
 def _cnt(scratch):

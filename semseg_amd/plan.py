@@ -5,7 +5,6 @@ Recording is transparent to the engine: while a StepPlan is `lib.recorder`, ever
 appended to the C-side plan (entry id + one 64-bit slot per argument).  What is not a C-ABI launch — a collective of
 torch.distributed (SyncBN exchange, gradient buckets) — is registered by the engine as a host operation
 (`StepPlan.py_op`); it ends the current C segment, so a replay is  segment, host op, segment, ...  in the recorded order.
-A plan with one segment and no host op (a single-GPU step) can additionally be captured into one hipGraph.
 
 A recorded argument must still mean the same thing at replay time.  Guaranteed by construction: the engine's buffers live as
 long as the engine (Engine.buf), streams are cached per device, per-step scalars are read from device memory
@@ -56,7 +55,6 @@ class StepPlan:
         self._seg_start = 0
         self._ids = {}
         self.error = None
-        self.graph = None
         self.recording = False
         self._append = lib.raw("semseg_plan_append")
         self._replay = lib.raw("semseg_plan_replay")
@@ -184,11 +182,6 @@ class StepPlan:
         return sum(1 for s in self.segments if s[0] == "py")
 
     def replay(self):
-        if self.graph is not None:
-            g, st = self.graph
-            if lib.raw("semseg_plan_graph_launch")(self.handle, g, st.cuda_stream) != 0:
-                raise PlanError("semseg_plan_graph_launch failed")
-            return
         for seg in self.segments:
             if seg[0] == "c":
                 rc = self._replay(self.handle, seg[1], seg[2])
@@ -200,18 +193,3 @@ class StepPlan:
             else:
                 with torch.cuda.stream(seg[2]):
                     seg[1]()
-
-    def capture_graph(self, origin):
-        """One hipGraph of the whole plan, launched on `origin` (a non-default torch stream).  Only for plans without host
-        operations.  Returns the number of graph nodes."""
-        if self.host_ops() or len(self.segments) != 1:
-            raise PlanError("a plan with host operations (collectives) cannot be one graph")
-        if origin.cuda_stream == 0:
-            raise PlanError("graph capture needs a non-default origin stream")
-        _, first, last = self.segments[0]
-        g = lib.raw("semseg_plan_graph_capture")(self.handle, first, last, origin.cuda_stream)
-        if g < 0:
-            raise PlanError("semseg_plan_graph_capture failed with code %d (entry %d)" %
-                            (g, lib.raw("semseg_plan_failed_entry")(self.handle)))
-        self.graph = (g, origin)
-        return lib.raw("semseg_plan_graph_nodes")(self.handle, g)

@@ -18,14 +18,13 @@ from . import engine as _engine
 from . import ops
 from ._lib import lib
 from .engine import Engine
+from ._lib import debug
 from .plan import PlanError, StepPlan
 
 # Step plan (semseg_amd/plan.py, csrc/plan.hip): after EAGER_STEPS eager steps of an engine the next TWO are recorded (they run
 # launch by launch, as before) and, when both records hold the same calls with the same arguments, every later step is
 # replayed from C.  SEMSEG_STEP_PLAN=0: every step is sequenced by Python, launch by launch (rounds 1-4).
-# SEMSEG_STEP_GRAPH=1: a recorded single-GPU step is additionally captured into one hipGraph.
 STEP_PLAN = os.environ.get("SEMSEG_STEP_PLAN", "1") != "0"
-STEP_GRAPH = os.environ.get("SEMSEG_STEP_GRAPH", "0") == "1"
 EAGER_STEPS = 2
 
 
@@ -52,7 +51,7 @@ class Trainer:
         self.bucket_elems = bucket_mb * 1024 * 1024 // 4
         self.grad_group = dist.new_group() if self.dist_on else None
         self.timers = None
-        self.use_plan, self.use_graph = STEP_PLAN, STEP_GRAPH
+        self.use_plan = STEP_PLAN
         self._step_state = torch.zeros(2, dtype=torch.float32, device=self.device)    # {lr, lr of the heads}: semseg_sgd_step's lr_dev
         self.plan_log = []        # what happened to every recording attempt (tests, bench)
 
@@ -87,12 +86,6 @@ class Trainer:
         if e is None:
             e = Engine(self.model, x.shape[0], x.shape[2], x.shape[3], True, self.model.kind)
             e.force_sync_bn = self.sync_bn and self.dist_on
-            if self.use_graph and os.environ.get("SEMSEG_GRAPH_KEEP_HIPRI") != "1":
-                # one level of forked streams inside a capture: the weight-gradient stream forks from the stream the step runs
-                # on.  (With the data-gradient chain on a second, high-priority stream the side stream is a fork of a fork, and
-                # hipStreamEndCapture of ROCm 7.0 crashes on the record — scripts/graph_debug.py; stream priorities mean
-                # nothing inside a graph anyway.)
-                e.hipri_main = False
             assert e.flat_grad.numel() == self.total
             if self.dist_on:
                 self._make_buckets(e)
@@ -150,9 +143,9 @@ class Trainer:
                 self._set_step_state(e, lr, 0)      # the device part of the dropout counter belongs to replayed steps only
             return self._fresh(e, self._step_eager(e, x, y, lr))
         # planned steps (the eager ones before the recording included) run on one stream of their own: a recorded stream handle
-        # must mean the same stream at every replay, and a graph cannot be captured on the default stream
+        # must mean the same stream at every replay
         cur = torch.cuda.current_stream()
-        if os.environ.get("SEMSEG_PLAN_OWN_STREAM", "1") == "0" and not self.use_graph:      # A/B only
+        if debug("plan_own_stream", "1") == "0":      # A/B only
             return self._fresh(e, self._step_planned(e, x, y, lr, cur))
         st = _engine._shared(self.device, "plan_stream", lambda: torch.cuda.Stream(device=self.device))
         ops.stream_wait(st, cur)
@@ -326,11 +319,6 @@ class Trainer:
         e._plan_sig = sig
         msg = "recorded: %d launches in %d segments, %d host operations; verified against the previous step's record" % (
             plan.launches(), len(plan.segments) - plan.host_ops(), plan.host_ops())
-        if self.use_graph and plan.host_ops() == 0:
-            try:
-                msg += "; hipGraph of %d nodes" % plan.capture_graph(st)
-            except PlanError as err:
-                msg += "; no graph (%s)" % err
         self.plan_log.append(msg)
         return out
 

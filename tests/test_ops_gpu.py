@@ -216,8 +216,7 @@ def test_wgrad_128_tile_variants(case, variant, report, monkeypatch):
     """Every variant of the 128 x 128 weight-gradient kernel (0 register-staged, 1-5 direct-to-LDS rings with
     out-of-range buffer offsets for padding taps / the K tail) against fp64; operands live in wider buffers."""
     from semseg_amd import ops
-    monkeypatch.setenv("SEMSEG_WGRAD_SMALL", "0")
-    monkeypatch.setenv("SEMSEG_WGRAD_DMA", str(variant))
+    monkeypatch.setenv("SEMSEG_DEBUG", "wgrad_small=0,wgrad_dma=%s" % variant)
     N, H, W, Ci, Co, k, s, p, d = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = torch.randn(N, Ci, H, W, generator=g)
@@ -780,7 +779,7 @@ def test_gemm_entry_points(report):
 def test_batched_gemm_entry_points(report):
     """torch.bmm of model/psanet.py:90-91 and its two gradients as ONE launch per GEMM (blockIdx.y = image): the
     batched forms of the two matrix-core kernels vs fp64, including accumulation into an existing dx and the
-    weight-gradient kernel variants (SEMSEG_WGRAD_DMA)."""
+    weight-gradient kernel variants (SEMSEG_DEBUG wgrad_dma)."""
     import os
     from semseg_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -806,11 +805,11 @@ def test_batched_gemm_entry_points(report):
     scratch = torch.empty(16 * 1024 * 1024, device=DEV)
     errs = []
     for v in ("0", "2"):
-        os.environ["SEMSEG_WGRAD_DMA"] = v
+        os.environ["SEMSEG_DEBUG"] = "wgrad_dma=" + v
         dXd = dX0.to(DEV).clone()
         ops.gemm_kmajor_batched(dZd, C, hw * C, Ad, P, hw * P, dXd, hw * C, scratch, hw, C, hw, B, accumulate=True)
         errs.append(relerr(dXd, dX))
-    os.environ.pop("SEMSEG_WGRAD_DMA")
+    os.environ.pop("SEMSEG_DEBUG")
     e = (relerr(Zd[..., C:], Z), relerr(dAd[:B * hw, :hw].view(B, hw, hw), dA), max(errs))
     report("batched psa contraction gemms (%d images, one launch each): fwd %.2e dA %.2e dX %.2e" % ((B,) + e))
     assert max(e) < 1e-5 and float(Zd[..., :C].abs().max()) == 0.0 and float(dAd[:, hw:].abs().max()) == 0.0
@@ -1149,10 +1148,10 @@ def test_conv_wgrad_arith_bf16x3(case, sp_variant, report, monkeypatch):
     piece planes, six bf16 matrix-core products) in its three gather modes (1x1, "same" 3x3 with dilation, strided)
     next to the fp32 kernels on the same operands, against fp64: rms within 2x of the fp32 path's (+1e-7)."""
     from semseg_amd import ops
-    monkeypatch.setenv("SEMSEG_WGRAD_SMALL", "0")          # keep the 128 x 128 path on these small grids
-    # 8 / 9: the direct-to-LDS ring with the split at fragment time (4 stages / 3 stages); 0: the register-staged SP kernel;
+    # wgrad_small=0: keep the 128 x 128 path on these small grids
+    # wgrad_sp 8 / 9: the direct-to-LDS ring with the split at fragment time (4 stages / 3 stages); 0: the register-staged SP kernel;
     # 10: the 128 x 256 kernel with 64 x 128 wave tiles (layers with Ci % 256 == 0, else variant 8)
-    monkeypatch.setenv("SEMSEG_WGRAD_SP", str(sp_variant))
+    monkeypatch.setenv("SEMSEG_DEBUG", "wgrad_small=0,wgrad_sp=%s" % sp_variant)
     N, H, W, Ci, Co, k, s_, p_, d = case
     g = torch.Generator().manual_seed(31)
     x = torch.relu(torch.randn(N, Ci, H, W, generator=g))
@@ -1180,7 +1179,7 @@ def test_conv_wgrad_arith_bf16x3(case, sp_variant, report, monkeypatch):
                                   (2, 15, 15, 256, 256, 1, 1, 0, 1)])    # a 128-multiple layer on a grid small enough for the 64 x 64 rule
 def test_conv_wgrad_arith_bf16x3_64_tiles(case, report, monkeypatch):
     """The SP instance of the 64 x 64 register-staged weight-gradient kernel (waves 0-1 stage dy, waves 2-3 stage x) under
-    SEMSEG_ARITH_BF16X3, next to the exact-fp32 64 x 64 kernel (SEMSEG_WGRAD_SP64=0) on the same operands, against fp64: rms
+    SEMSEG_ARITH_BF16X3, next to the exact-fp32 64 x 64 kernel (SEMSEG_DEBUG wgrad_sp64=0) on the same operands, against fp64: rms
     within 2x of the fp32 kernel's (+1e-7), the criterion of the 128 x 128 instances."""
     from semseg_amd import ops
     N, H, W, Ci, Co, k, s_, p_, d = case
@@ -1198,7 +1197,7 @@ def test_conv_wgrad_arith_bf16x3_64_tiles(case, report, monkeypatch):
     rms = lambda a: float((a.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     errs = []
     for sp64 in ("0", "1"):
-        monkeypatch.setenv("SEMSEG_WGRAD_SP64", sp64)
+        monkeypatch.setenv("SEMSEG_DEBUG", "wgrad_sp64=" + sp64)
         dw = torch.full((Co, Ci, k, k), float("nan"), device=DEV)
         ops.conv_wgrad(xd, ldx, dyd, ldy, dw, scratch, N, H, W, Ci, Co, k, k, s_, p_, d, arith=ops.ARITH_BF16X3)
         torch.cuda.synchronize()
