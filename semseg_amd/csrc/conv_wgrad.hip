@@ -607,6 +607,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
 // four waves and 96 KB per CU leave that chain the issue slots and the LDS that eight waves and 128 KB did not.
 // x rows are 256 floats = 1 KiB = one wave-instruction per pixel, so the gather decode of a DMA instruction is wave-uniform.
 // ------------------------------------------------------------------------------------------
+#ifndef WGRAD_WIDE_SPLIT_ACC
+#define WGRAD_WIDE_SPLIT_ACC 0     // 1: a second accumulator set for the five small cross products (A/B builds; see the kernel)
+#endif
 template <int MODE, int NSTAGE>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const WgradArgs pin) {
   WgradArgs p = pin;
@@ -702,13 +705,29 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
     }
   };
 
+  // WGRAD_WIDE_SPLIT_ACC = 1 (round 6, a build option, NOT the default): the LEADING product (high piece x high piece) of every K step
+  // goes into `acc`, the five small cross products (2^-9 ... 2^-18 of it) into a second set `accs`, added once at the end.  Why it
+  // exists: the bf16 matrix-core instruction costs the accumulator it adds into ~0.3 ulp of noise per PRODUCT, whatever the size of
+  // the product, so with one set the six instructions of a K step put sqrt(6) x the leading product's noise on the sum.  Measured
+  // (scripts/wgrad_noise.py, 55 696-pixel reductions, random operands, rms against fp64): exact fp32 products 3.1e-7, bf16x3 with one
+  // set 5.6e-7 (Ci 512) / 7.5e-7 (Ci 1024), with two sets 2.0e-7 / 2.2e-7 — below the exact path.  It is what puts five 1x1 weight
+  // gradients of PSANet-101 at batch 16 at 3.1-4.2 x the CPU-fp32 noise in situ (criterion 3 x).  Price: 256
+  // accumulator registers, the kernel sits at 512 with spills: 114.4 -> 119.5 ms per batch-16 step (+4.5 %).  The default stays one set.
   f32x16 acc[2][4];
+#if WGRAD_WIDE_SPLIT_ACC
+  f32x16 accs[2][4];
+#endif
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+#if WGRAD_WIDE_SPLIT_ACC
+        accs[i][j][e] = 0.f;
+#endif
+      }
 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   // raw fp32 fragments of a stage: the 8 pixels of this lane's k-group for its 2 dy rows (2 l31 + i) and 4 x columns (4 l31 + j)
@@ -752,8 +771,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+#if WGRAD_WIDE_SPLIT_ACC
+          if (q < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i][PA[q]], fb2[j][PB[q]], accs[i][j], 0, 0, 0);
+          else
+#endif
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i][PA[q]], fb2[j][PB[q]], acc[i][j], 0, 0, 0);
+        }
   };
 
   const int nsteps = (kend - kbeg + KS - 1) / KS;
@@ -792,6 +816,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
     nslot_ = nslot_ + 1 == NSTAGE ? 0 : nslot_ + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the workgroup has retired
+#if WGRAD_WIDE_SPLIT_ACC
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] += accs[i][j][e];
+#endif
 
   float* out = p.dw + (size_t)ks * p.Co_pad * RS * p.Ci;
   const int ci = ci0 + wn * 128 + 4 * l31;
