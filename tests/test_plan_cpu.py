@@ -149,3 +149,14 @@ def test_only_the_recording_thread_is_recorded():
     lib.semseg_host_probe(addr, 4, 5, 6, 0.0, 0.0, None)
     assert plan.end() is None
     assert out[6] == 3 and plan.launches() == 2
+
+
+def test_debug_switch_list(monkeypatch):
+    """SEMSEG_DEBUG = "name=value,name=value": the one variable every A/B / test switch lives in (semseg_amd._lib.debug; the C side
+    parses the same string, csrc/common.h semseg_debug)."""
+    from semseg_amd._lib import debug
+    monkeypatch.delenv("SEMSEG_DEBUG", raising=False)
+    assert debug("side_wgrad") is None and debug("side_wgrad", "1") == "1"
+    monkeypatch.setenv("SEMSEG_DEBUG", "side_wgrad=0, wgrad_dma=1:3:32 ,fused_split_max=4")
+    assert debug("side_wgrad", "1") == "0" and debug("wgrad_dma") == "1:3:32" and debug("fused_split_max") == "4"
+    assert debug("wgrad") is None and debug("hipri_main", "1") == "1"
