@@ -607,6 +607,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
 // four waves and 96 KB per CU leave that chain the issue slots and the LDS that eight waves and 128 KB did not.
 // x rows are 256 floats = 1 KiB = one wave-instruction per pixel, so the gather decode of a DMA instruction is wave-uniform.
 // ------------------------------------------------------------------------------------------
+#ifndef WGRAD_WIDE_INTERLEAVE
+#define WGRAD_WIDE_INTERLEAVE 1     // 0: sp_mfma + sp_split in the compiler's own order (rounds 4-5; A/B builds)
+#endif
 #ifndef WGRAD_WIDE_SPLIT_ACC
 #define WGRAD_WIDE_SPLIT_ACC 0     // 1: a second accumulator set for the five small cross products (A/B builds; see the kernel)
 #endif
@@ -712,7 +715,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
   // (scripts/wgrad_noise.py, 55 696-pixel reductions, random operands, rms against fp64): exact fp32 products 3.1e-7, bf16x3 with one
   // set 5.6e-7 (Ci 512) / 7.5e-7 (Ci 1024), with two sets 2.0e-7 / 2.2e-7 — below the exact path.  It is what puts five 1x1 weight
   // gradients of PSANet-101 at batch 16 at 3.1-4.2 x the CPU-fp32 noise in situ (criterion 3 x).  Price: 256
-  // accumulator registers, the kernel sits at 512 with spills: 114.4 -> 119.5 ms per batch-16 step (+4.5 %).  The default stays one set.
+  // accumulator registers: 113.8 -> 116.0 ms per batch-16 step (+2.0 %) on the interleaved loop below (+4.5 % on the compiler-scheduled loop of
+  // rounds 4-5, where the kernel sat at 512 registers with spills).  The default stays one set.
   f32x16 acc[2][4];
 #if WGRAD_WIDE_SPLIT_ACC
   f32x16 accs[2][4];
@@ -793,6 +797,107 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
     sp_split(ya, xa, fca, fcb);
   }
   int nslot_ = 1, pslot_ = NSTAGE - 1;
+#if WGRAD_WIDE_INTERLEAVE
+  // One wave per SIMD: nothing but this wave's OWN VALU work can run under its matrix-core instructions, and a wave issues in order —
+  // the 48 matrix-core instructions of a stage (32 cycles each) and the ~290 VALU instructions that split the next stage's fragments
+  // (4 cycles each) overlap only where they ALTERNATE in the instruction stream.  Left to itself the compiler emits the 48 in runs of
+  // 11-18 and ~215 VALU instructions behind the last one (ISA of rounds 4-5: the matrix pipe was busy 0.48 of the kernel); a
+  // sched_group_barrier pipeline is dropped by its solver after ~11 groups.  So the stage is written as 48 slots — one matrix-core
+  // instruction + one ~10-instruction piece of the split — with a scheduling barrier behind each slot.  The split of a vector of 8
+  // floats is cut into 5 pieces (first / second bf16 piece of either half: convert, widen, subtract; third piece: convert): 30 pieces,
+  // five in every eight slots.  The two fragment sets swap roles from stage to stage (no copies).
+  auto split_piece = [&](int c, f32x2 (&ya)[8], f32x4 (&xa)[8], bf16x4 (&pa)[2][3][2], bf16x4 (&pb)[4][3][2]) {
+    if (c < 24) {
+      const int ph = c / 12, cc = c - 12 * ph, h = cc / 6, v = cc - 6 * h;
+      f32x4 x;
+      if (v < 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = ya[4 * h + k][v];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = xa[4 * h + k][v - 2];
+      }
+      bf16x4 pc = __builtin_convertvector(x, bf16x4);
+      f32x4 r = x - bf16x4_to_f32(pc);
+      // (an empty volatile asm on the results: the optimiser otherwise sinks this arithmetic to its first use — the NEXT stage's
+      // matrix-core instructions — long before the machine scheduler sees the scheduling barriers)
+      asm volatile("" : "+v"(pc), "+v"(r));
+      if (v < 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ya[4 * h + k][v] = r[k];
+        pa[v][ph][h] = pc;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xa[4 * h + k][v - 2] = r[k];
+        pb[v - 2][ph][h] = pc;
+      }
+    } else if (c < 30) {
+      const int v = c - 24;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 x;
+        if (v < 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = ya[4 * h + k][v];
+          bf16x4 pc = __builtin_convertvector(x, bf16x4);
+          asm volatile("" : "+v"(pc));
+          pa[v][2][h] = pc;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = xa[4 * h + k][v - 2];
+          bf16x4 pc = __builtin_convertvector(x, bf16x4);
+          asm volatile("" : "+v"(pc));
+          pb[v - 2][2][h] = pc;
+        }
+      }
+    }
+  };
+  auto stage_body = [&](int t, const bf16x8 (&ca)[2][3], const bf16x8 (&cb)[4][3], bf16x8 (&na)[2][3], bf16x8 (&nb)[4][3]) {
+    // stage t + 1 has landed for this wave once at most NSTAGE - 3 younger stages are outstanding, for every wave after the
+    // barrier — which also says that everybody finished reading stage t (in iteration t - 1): its slot may be overwritten
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NIY + NIX) * (NSTAGE - 3)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(kbeg + (t + NSTAGE - 1) * KS, pslot_);
+    f32x2 ya[8];
+    f32x4 xa[8];
+    bf16x4 pa[2][3][2], pb[4][3][2];
+    sp_read(nslot_, ya, xa);        // stage t + 1 (past the end of the split: another split's rows or zeros, never used)
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int sl = 0; sl < 48; ++sl) {
+      const int q = sl / 8, i = (sl & 7) >> 2, j = sl & 3;
+#if WGRAD_WIDE_SPLIT_ACC
+      if (q < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i][PA[q]], cb[j][PB[q]], accs[i][j], 0, 0, 0);
+      else
+#endif
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i][PA[q]], cb[j][PB[q]], acc[i][j], 0, 0, 0);
+      // 30 pieces over 48 slots, five per eight (a piece is ~40 cycles of VALU work, a matrix-core instruction 32): slots 0, 2, 4, 5, 7 of every eight
+      constexpr int PRE[8] = {0, 1, 1, 2, 2, 3, 4, 4};
+      const int r8 = sl & 7;
+      if (r8 == 0 || r8 == 2 || r8 == 4 || r8 == 5 || r8 == 7) split_piece((sl >> 3) * 5 + PRE[r8], ya, xa, pa, pb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) na[i][pc] = __builtin_shufflevector(pa[i][pc][0], pa[i][pc][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nb[j][pc] = __builtin_shufflevector(pb[j][pc][0], pb[j][pc][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    pslot_ = pslot_ + 1 == NSTAGE ? 0 : pslot_ + 1;
+    nslot_ = nslot_ + 1 == NSTAGE ? 0 : nslot_ + 1;
+  };
+  {
+    bf16x8 fda[2][3], fdb[4][3];
+    int t = 0;
+    for (; t + 1 < nsteps; t += 2) {
+      stage_body(t, fca, fcb, fda, fdb);
+      stage_body(t + 1, fda, fdb, fca, fcb);
+    }
+    if (t < nsteps) stage_body(t, fca, fcb, fda, fdb);
+  }
+#else
   for (int t = 0; t < nsteps; ++t) {
     // stage t + 1 has landed for this wave once at most NSTAGE - 3 younger stages are outstanding, for every wave after the
     // barrier — which also says that everybody finished reading stage t (in iteration t - 1): its slot may be overwritten
@@ -815,6 +920,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
     pslot_ = pslot_ + 1 == NSTAGE ? 0 : pslot_ + 1;
     nslot_ = nslot_ + 1 == NSTAGE ? 0 : nslot_ + 1;
   }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the workgroup has retired
 #if WGRAD_WIDE_SPLIT_ACC
 #pragma unroll
