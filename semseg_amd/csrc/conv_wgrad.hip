@@ -610,10 +610,10 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_dma_kernel(const WgradArg
 #ifndef WGRAD_WIDE_INTERLEAVE
 #define WGRAD_WIDE_INTERLEAVE 1     // 0: sp_mfma + sp_split in the compiler's own order (rounds 4-5; A/B builds)
 #endif
-#ifndef WGRAD_WIDE_SPLIT_ACC
-#define WGRAD_WIDE_SPLIT_ACC 0     // 1: a second accumulator set for the five small cross products (A/B builds; see the kernel)
+#ifndef WGRAD_ACC2_MIN_M
+#define WGRAD_ACC2_MIN_M 16384     // 1x1 weight gradients with a longer reduction run the two-accumulator instance (ACC2; see the kernel); 0x7fffffff: never (A/B builds)
 #endif
-template <int MODE, int NSTAGE>
+template <int MODE, int NSTAGE, int ACC2 = 0>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const WgradArgs pin) {
   WgradArgs p = pin;
   if (p.batch > 1) {
@@ -708,19 +708,17 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
     }
   };
 
-  // WGRAD_WIDE_SPLIT_ACC = 1 (round 6, a build option, NOT the default): the LEADING product (high piece x high piece) of every K step
-  // goes into `acc`, the five small cross products (2^-9 ... 2^-18 of it) into a second set `accs`, added once at the end.  Why it
-  // exists: the bf16 matrix-core instruction costs the accumulator it adds into ~0.3 ulp of noise per PRODUCT, whatever the size of
-  // the product, so with one set the six instructions of a K step put sqrt(6) x the leading product's noise on the sum.  Measured
-  // (scripts/wgrad_noise.py, 55 696-pixel reductions, random operands, rms against fp64): exact fp32 products 3.1e-7, bf16x3 with one
-  // set 5.6e-7 (Ci 512) / 7.5e-7 (Ci 1024), with two sets 2.0e-7 / 2.2e-7 — below the exact path.  It is what puts five 1x1 weight
-  // gradients of PSANet-101 at batch 16 at 3.1-4.2 x the CPU-fp32 noise in situ (criterion 3 x).  Price: 256
-  // accumulator registers: 113.8 -> 116.0 ms per batch-16 step (+2.0 %) on the interleaved loop below (+4.5 % on the compiler-scheduled loop of
-  // rounds 4-5, where the kernel sat at 512 registers with spills).  The default stays one set.
+  // ACC2 = 1 (round 6; the instance 1x1 weight gradients with reductions longer than WGRAD_ACC2_MIN_M pixels run): the LEADING product
+  // (high piece x high piece) of every K step goes into `acc`, the five small cross products (2^-9 ... 2^-18 of it) into a second
+  // set `accs`, added once at the end.  Why: the bf16 matrix-core instruction costs the accumulator it adds into ~0.3 ulp of noise
+  // per PRODUCT, whatever the size of the product, so with one set the six instructions of a K step put sqrt(6) x the leading
+  // product's noise on the sum.  Measured (scripts/wgrad_noise.py, 55 696-pixel reductions, random operands, rms against fp64):
+  // exact fp32 products 3.1e-7, bf16x3 with one set 5.6e-7 (Ci 512) / 7.5e-7 (Ci 1024), with two sets 2.0e-7 / 2.2e-7 — below the
+  // exact path.  One set put five 1x1 weight gradients of PSANet-101 at batch 16 at 3.1-4.2 x the CPU-fp32 noise in situ (criterion
+  // 3 x).  Price: 256 accumulator registers (one wave per SIMD: they are there), +9 % per launch — paid where
+  // the accumulator noise is what limits the result (long single reductions), not by the batched Winograd-domain launches (1.3 x).
   f32x16 acc[2][4];
-#if WGRAD_WIDE_SPLIT_ACC
-  f32x16 accs[2][4];
-#endif
+  f32x16 accs[ACC2 ? 2 : 1][ACC2 ? 4 : 1];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -728,9 +726,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         acc[i][j][e] = 0.f;
-#if WGRAD_WIDE_SPLIT_ACC
-        accs[i][j][e] = 0.f;
-#endif
+        if constexpr (ACC2) accs[i][j][e] = 0.f;
       }
 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -776,11 +772,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#if WGRAD_WIDE_SPLIT_ACC
-          if (q < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i][PA[q]], fb2[j][PB[q]], accs[i][j], 0, 0, 0);
-          else
-#endif
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i][PA[q]], fb2[j][PB[q]], acc[i][j], 0, 0, 0);
+          if (ACC2 && q < 5) accs[ACC2 ? i : 0][ACC2 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i][PA[q]], fb2[j][PB[q]], accs[ACC2 ? i : 0][ACC2 ? j : 0], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i][PA[q]], fb2[j][PB[q]], acc[i][j], 0, 0, 0);
         }
   };
 
@@ -867,11 +860,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
 #pragma unroll
     for (int sl = 0; sl < 48; ++sl) {
       const int q = sl / 8, i = (sl & 7) >> 2, j = sl & 3;
-#if WGRAD_WIDE_SPLIT_ACC
-      if (q < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i][PA[q]], cb[j][PB[q]], accs[i][j], 0, 0, 0);
-      else
-#endif
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i][PA[q]], cb[j][PB[q]], acc[i][j], 0, 0, 0);
+      if (ACC2 && q < 5) accs[ACC2 ? i : 0][ACC2 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i][PA[q]], cb[j][PB[q]], accs[ACC2 ? i : 0][ACC2 ? j : 0], 0, 0, 0);
+      else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i][PA[q]], cb[j][PB[q]], acc[i][j], 0, 0, 0);
       // 30 pieces over 48 slots, five per eight (a piece is ~40 cycles of VALU work, a matrix-core instruction 32): slots 0, 2, 4, 5, 7 of every eight
       constexpr int PRE[8] = {0, 1, 1, 2, 2, 3, 4, 4};
       const int r8 = sl & 7;
@@ -922,14 +912,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_wide_kernel(const Wgrad
   }
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the workgroup has retired
-#if WGRAD_WIDE_SPLIT_ACC
+  if constexpr (ACC2) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] += accs[i][j][e];
-#endif
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += accs[i][j][e];
+  }
 
   float* out = p.dw + (size_t)ks * p.Co_pad * RS * p.Ci;
   const int ci = ci0 + wn * 128 + 4 * l31;
@@ -1135,7 +1125,9 @@ static int wgrad_launch(const float* x, int ldx, const float* dy, int lddy, floa
     else conv_wgrad_dma_kernel<0, 16, NST_, OCC_, false, 3><<<grid, 256, 0, stream>>>(a);                 \
   } while (0)
   if (sp && sp_dma == 10) {
-    if (mode == 1) conv_wgrad_dma_wide_kernel<1, WIDE_NSTAGE><<<grid, 256, 0, stream>>>(a);
+    // long single 1x1 reductions: the two-accumulator instance (mode 1 = the 1x1 gather; batched launches are the Winograd-domain GEMMs)
+    if (mode == 1 && batch == 1 && M > WGRAD_ACC2_MIN_M) conv_wgrad_dma_wide_kernel<1, WIDE_NSTAGE, 1><<<grid, 256, 0, stream>>>(a);
+    else if (mode == 1) conv_wgrad_dma_wide_kernel<1, WIDE_NSTAGE><<<grid, 256, 0, stream>>>(a);
     else if (mode == 2) conv_wgrad_dma_wide_kernel<2, WIDE_NSTAGE><<<grid, 256, 0, stream>>>(a);
     else conv_wgrad_dma_wide_kernel<0, WIDE_NSTAGE><<<grid, 256, 0, stream>>>(a);
   } else if (sp && sp_dma == 8) LAUNCH_WGRAD_DMA_SP(4, 2);
